@@ -1,0 +1,68 @@
+"""Case tables shared by the golden generator and the parity tests (data only)."""
+
+HEADS = [3, 6, 12, 24]
+
+
+def _cfg(img, p, dim, depths, window, self_cond=True):
+    return dict(img_size=img, patch_size=p, in_chans=1, embed_dim=dim, depths=depths, num_heads=HEADS,
+                window_size=window, self_condition=self_cond)
+
+
+# G1: WindowAttention.  mask_res != 0 -> use the shift mask of a res x res block (B_ must be k * nW)
+ATTN_CASES = {
+    "w6_c96": dict(C=96, w=6, heads=3, B_=8, mask_res=0, seed=11),
+    "w6_c96_mask": dict(C=96, w=6, heads=3, B_=8, mask_res=12, seed=12),      # 4 windows x 2
+    "w8_c192_mask": dict(C=192, w=8, heads=6, B_=4, mask_res=16, seed=13),
+    "w4_c60": dict(C=60, w=4, heads=3, B_=3, mask_res=0, seed=14),            # head_dim 20
+}
+
+# G2/G3: SwinTransformerBlock
+BLOCK_CASES = {
+    "r12_w6_s0": dict(C=96, res=12, heads=3, window=6, shift=0, B=2, seed=21),
+    "r12_w6_s3": dict(C=96, res=12, heads=3, window=6, shift=3, B=2, seed=22),
+    "r18_w6_s3_c192": dict(C=192, res=18, heads=6, window=6, shift=3, B=1, seed=23),
+    "r16_w8_s4": dict(C=96, res=16, heads=3, window=8, shift=4, B=2, seed=24),
+    "r8_w24_clamp": dict(C=96, res=8, heads=3, window=24, shift=12, B=3, seed=25),   # clamp -> w=8, s=0
+    "r2_w24_c240": dict(C=240, res=2, heads=12, window=24, shift=0, B=3, seed=26),   # 4-token window, hd 20
+    "r6_w6_c768": dict(C=768, res=6, heads=24, window=6, shift=3, B=2, seed=27),     # res == w -> shift forced 0
+}
+
+# G4: PatchMerging (res, C) and PatchBreakup (res/2, dim=4C)
+MERGE_CASES = {
+    "r12_c96": dict(C=96, res=12, B=2, seed=31),
+    "r8_c60": dict(C=60, res=8, B=2, seed=32),
+    "r4_c384": dict(C=384, res=4, B=1, seed=33),
+}
+
+# G5: PatchEmbed
+EMBED_CASES = {
+    "p4_in2": dict(N=48, p=4, **{"in": 2}, C=96, B=2, seed=41),
+    "p3_in2": dict(N=24, p=3, **{"in": 2}, C=60, B=2, seed=42),
+    "p1_in24": dict(N=16, p=1, **{"in": 24}, C=96, B=2, seed=43),
+}
+
+# G6/G7: full SwinGNN / Precond.  regimes: see oracle/filler.py
+NET_CASES = {
+    # ego-small / community-small geometry (config/edm_swin_gnn/ego_small..., com_small...)
+    "ego60": dict(cfg=_cfg(24, 3, 60, [4, 4, 6], 24), B=4, n_lo=4, n_hi=18, sigmas=[0.05, 1.0, 40.0],
+                  regimes=["init", "stress"], seed=51),
+    "com96": dict(cfg=_cfg(24, 3, 96, [4, 4, 6], 24), B=4, n_lo=12, n_hi=20, sigmas=[0.5, 10.0],
+                  regimes=["init", "stress"], seed=52),
+    # reduced grid geometry that still reaches the shifted path: token sides 48/24/12/6
+    "grid192": dict(cfg=_cfg(192, 4, 96, [1, 1, 3, 1], 6), B=2, n_lo=100, n_hi=181, sigmas=[0.2, 5.0],
+                    regimes=["init", "stress"], seed=53),
+    # reduced DD geometry: token sides 64/32/16/8, w=8
+    "dd256": dict(cfg=_cfg(256, 4, 96, [1, 1, 3, 1], 8), B=1, n_lo=130, n_hi=250, sigmas=[2.0],
+                  regimes=["init"], seed=54),
+    # no self-conditioning (in_chans stays 1)
+    "ego60_nosc": dict(cfg=_cfg(24, 3, 60, [4, 4, 6], 24, self_cond=False), B=2, n_lo=4, n_hi=18, sigmas=[1.0],
+                       regimes=["stress"], seed=55),
+}
+
+# G8: EDMSampler.sample (CPU torch generator + numpy coin, both seeded with `seed`)
+SAMPLER_CASES = {
+    "ego60_8": dict(net="ego60", regime="init", steps=8, B=3, n_lo=4, n_hi=18, sanity=False, seed=61),
+    "ego60_256": dict(net="ego60", regime="init", steps=256, B=2, n_lo=4, n_hi=18, sanity=False, seed=62),
+    "ego60_sanity": dict(net="ego60", regime="init", steps=16, B=3, n_lo=4, n_hi=18, sanity=True, seed=63),
+    "grid192_4": dict(net="grid192", regime="init", steps=4, B=1, n_lo=100, n_hi=181, sanity=False, seed=64),
+}

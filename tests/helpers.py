@@ -1,0 +1,80 @@
+"""Shared builders for the parity tests: regenerate the weights / inputs of a golden case."""
+import numpy as np
+import torch
+
+from oracle import filler
+from oracle import swingnn_ref as O
+
+
+def block_state(C, heads, w, seed, prefix="blk", regime="stress"):
+    """State dict of one SwinTransformerBlock with the reference's key names and shapes."""
+    sd = {
+        "affine.weight": (2 * C, 512), "affine.bias": (2 * C,),
+        "norm1.weight": (C,), "norm1.bias": (C,),
+        "attn.relative_position_bias_table": ((2 * w - 1) ** 2, heads),
+        "attn.qkv.weight": (3 * C, C), "attn.qkv.bias": (3 * C,),
+        "attn.proj.weight": (C, C), "attn.proj.bias": (C,),
+        "norm2.weight": (C,), "norm2.bias": (C,),
+        "mlp.fc1.weight": (4 * C, C), "mlp.fc1.bias": (4 * C,),
+        "mlp.fc2.weight": (C, 4 * C), "mlp.fc2.bias": (C,),
+    }
+    # buffers are part of the reference state dict; the filler leaves them untouched, and key order
+    # matters for nothing because the filler hashes by key name
+    zeros = {k: torch.zeros(s) for k, s in sd.items()}
+    zeros["attn.relative_position_index"] = O.relative_position_index(w)
+    filled = filler.fill_state_dict(zeros, seed, regime)
+    return {f"{prefix}.{k}": v for k, v in filled.items()}
+
+
+def attn_state(C, heads, w, seed, prefix="attn"):
+    shapes = {
+        "relative_position_bias_table": ((2 * w - 1) ** 2, heads),
+        "qkv.weight": (3 * C, C), "qkv.bias": (3 * C,), "proj.weight": (C, C), "proj.bias": (C,),
+    }
+    zeros = {k: torch.zeros(s) for k, s in shapes.items()}
+    zeros["relative_position_index"] = O.relative_position_index(w)
+    return {f"{prefix}.{k}": v for k, v in filler.fill_state_dict(zeros, seed, "stress").items()}
+
+
+def merge_state(C, seed, prefix="m"):
+    zeros = {"reduction.weight": torch.zeros(2 * C, 4 * C), "norm.weight": torch.zeros(4 * C), "norm.bias": torch.zeros(4 * C)}
+    return {f"{prefix}.{k}": v for k, v in filler.fill_state_dict(zeros, seed, "stress").items()}
+
+
+def breakup_state(dim, seed, prefix="u"):
+    Co = dim // 4
+    zeros = {"pre_linear.weight": torch.zeros(dim, dim), "norm.weight": torch.zeros(dim), "norm.bias": torch.zeros(dim),
+             "post_linear.weight": torch.zeros(Co, Co), "post_norm.weight": torch.zeros(Co), "post_norm.bias": torch.zeros(Co)}
+    return {f"{prefix}.{k}": v for k, v in filler.fill_state_dict(zeros, seed, "stress").items()}
+
+
+def embed_state(C, cin, p, seed, prefix="pe"):
+    zeros = {"affine.weight": torch.zeros(2 * C, 512), "affine.bias": torch.zeros(2 * C),
+             "proj.weight": torch.zeros(C, cin, p, p), "proj.bias": torch.zeros(C),
+             "norm.weight": torch.zeros(C), "norm.bias": torch.zeros(C)}
+    return {f"{prefix}.{k}": v for k, v in filler.fill_state_dict(zeros, seed, "stress").items()}
+
+
+def net_state(meta_keys, seed, regime):
+    """Full Precond(SwinGNN) state dict from the golden key/shape table (prefix 'model.')."""
+    dt = {"torch.float32": torch.float32, "torch.int64": torch.int64}
+    zeros = {}
+    for k, (shape, dtype) in meta_keys.items():
+        zeros[k] = torch.zeros(shape, dtype=dt[dtype])
+    # integer / mask buffers are recomputed by whoever consumes the dict; fill only floats
+    return filler.fill_state_dict(zeros, seed, regime)
+
+
+def net_inputs(case, si):
+    cfg = case["cfg"]
+    B, N, seed = case["B"], cfg["img_size"], case["seed"]
+    sigma = case["sigmas"][si]
+    flags = filler.node_flags("flags", B, N, case["n_lo"], case["n_hi"], seed)
+    x = filler.sym_adj("x", B, N, flags, seed + si, scale=float(np.sqrt(sigma ** 2 + 0.25)))
+    sig = torch.full((B,), float(sigma)) * (1.0 + 0.1 * filler.uniform("sig", (B,), seed)).abs()
+    sc = filler.sym_adj("sc", B, N, flags, seed + 100 + si, scale=0.5)
+    return flags, x, sig, sc
+
+
+def max_abs(a, b):
+    return float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max())
