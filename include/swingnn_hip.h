@@ -1,0 +1,172 @@
+/* libswingnn_hip.so -- C-ABI of the MI355X (gfx950) SwinGNN denoiser hot path.
+ *
+ * Plain pointers and sizes only; no C++ or torch types cross this boundary.
+ * All pointers are DEVICE pointers (contiguous, row-major) unless a comment says "host".
+ * `stream` is a hipStream_t passed as void*.  No entry point allocates, frees or
+ * synchronises: scratch memory comes in through (ws, ws_bytes), sized by
+ * swg_workspace_bytes().  Return value: 0 ok; <0 SWG_E_* (bad shape / unsupported
+ * config / workspace too small); >0 a hipError_t from a launch.
+ *
+ * Citations are file:line under the reference tree (DSL-Lab/SwinGNN).
+ * Activations between entry points: fp32 residual stream [B, L, C]; bf16 is used only
+ * for MFMA operands inside the library.
+ */
+#ifndef SWINGNN_HIP_H
+#define SWINGNN_HIP_H
+
+#include <stddef.h>
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define SWG_E_SHAPE (-1)       /* inconsistent or unsupported shape                       */
+#define SWG_E_UNSUPPORTED (-2) /* configuration outside what the kernels implement        */
+#define SWG_E_WORKSPACE (-3)   /* ws_bytes smaller than swg_workspace_bytes()             */
+#define SWG_E_NULL (-4)        /* a required pointer is NULL                              */
+
+#define SWG_NOISE_EMB 512 /* noise embedding width, model/swin_gnn/swin_gnn.py:634 */
+
+/* nn.Linear as the kernels consume it: weight converted to bf16 and zero-padded along K to
+ * Kp (a multiple of 32); bias stays fp32.  A derived cache of the fp32 nn.Parameter. */
+typedef struct swg_lin {
+  const void* w;  /* bf16 [N, Kp] row-major */
+  const float* b; /* [N] or NULL            */
+  int32_t N, K, Kp;
+} swg_lin;
+
+/* nn.LayerNorm(dim), eps 1e-5 */
+typedef struct swg_ln {
+  const float* g; /* weight [dim] */
+  const float* b; /* bias   [dim] */
+} swg_ln;
+
+/* SwinTransformerBlock (model/swin_gnn/swin_gnn.py:158-277).  win/shift are the EFFECTIVE
+ * values after the clamp rule of :189-192. */
+typedef struct swg_block {
+  int32_t C, res, win, shift, heads;
+  int32_t cond_off; /* offset of this block's (scale | shift), 2C floats, inside a cond row */
+  swg_ln ln1, ln2;
+  swg_lin qkv, proj, fc1, fc2;
+  const float* rpb; /* relative_position_bias_table [(2win-1)^2, heads] fp32, :84-85 */
+} swg_block;
+
+/* PatchMerging (:298-335) at input resolution res x res, input width C */
+typedef struct swg_merge {
+  int32_t C, res;
+  swg_ln ln;   /* LayerNorm(4C) */
+  swg_lin red; /* Linear(4C -> 2C), no bias */
+} swg_merge;
+
+/* PatchBreakup (:347-403) at input resolution res x res, input width Cin = 4C' */
+typedef struct swg_breakup {
+  int32_t Cin, res;
+  swg_lin pre;    /* Linear(4C' -> 4C'), no bias */
+  swg_ln ln;      /* LayerNorm(4C') */
+  swg_ln post_ln; /* LayerNorm(C')  */
+  swg_lin post;   /* Linear(C' -> C'), no bias */
+} swg_breakup;
+
+/* BasicLayer (:415-483): [upsample] -> blocks -> [downsample] */
+typedef struct swg_layer {
+  int32_t n_blocks;
+  int32_t is_decoder;
+  const swg_block* blocks; /* host pointer to n_blocks entries */
+  const swg_merge* down;   /* host pointer or NULL */
+  const swg_breakup* up;   /* host pointer or NULL */
+} swg_layer;
+
+/* SwinGNN (:587-779) */
+typedef struct swg_net {
+  int32_t N;         /* img_size = max_node_num                         */
+  int32_t p;         /* patch size                                      */
+  int32_t in_ch;     /* conv input channels (2 with self-conditioning)  */
+  int32_t C0;        /* embed_dim                                       */
+  int32_t n_layers;  /* 2 * len(depths): encoder layers then decoder    */
+  int32_t self_cond; /* SwinGNN.self_condition                          */
+  int32_t cond_total;/* sum over patch_embed + all blocks of 2C         */
+  int32_t pe_cond_off;
+  /* noise embedding: PositionalEmbedding freqs (:508-510) and the two mapping layers (:705-706) */
+  const float* freqs; /* [C0/2] */
+  const float *map0_w, *map0_b; /* [512, C0], [512] */
+  const float *map1_w, *map1_b; /* [512, 512], [512] */
+  /* every `affine` layer stacked: rows [cond_off, cond_off+2C) belong to one block (:195, :554) */
+  const float *aff_w, *aff_b; /* [cond_total, 512], [cond_total] */
+  /* PatchEmbed (:516-577) */
+  const float *pe_w, *pe_b; /* conv weight [C0, in_ch*p*p], bias [C0] */
+  swg_ln pe_ln;
+  const swg_layer* layers; /* host pointer to n_layers entries */
+  swg_ln norm;             /* final LayerNorm (:708) */
+  /* read_out (:697-701) collapsed to one affine map per token (no non-linearity between the
+   * three convolutions): out[Y*p+i, X*p+j] = sum_c tok[c] * ro_w[c, i*p+j] + ro_b */
+  const float* ro_w; /* [C0, p*p] */
+  float ro_b;
+} swg_net;
+
+/* ---- library ------------------------------------------------------------------------- */
+int swg_version(void);
+/* Bytes of scratch that swg_precond_forward / the op entry points need for batch B. */
+size_t swg_workspace_bytes(const swg_net* net, int32_t B);
+
+/* ---- whole network pass -------------------------------------------------------------- *
+ * mode 1: Precond.forward core, model/precond/precond.py:47-51 (edm branch of
+ *         runner/objectives/edm.py:122-126): D = mask(c_skip*x + c_out*F(c_in*x, ln(sigma)/4, self_cond)).
+ * mode 0: SwinGNN.forward, model/swin_gnn/swin_gnn.py:755-779: `labels` are the noise labels,
+ *         x is used as given, output = sym(mask(F)).
+ * labels: [B], or one value when labels_uniform != 0 (the sampler's case, mcmc_sampler/edm.py:180).
+ * self_cond may be NULL (zeros channel, :770).  sym_err (nullable): device float that
+ * accumulates sum|D - D^T| (the quantity asserted in utils/graph_utils.py:89-94). */
+int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float* x, const float* node_flags,
+                        const float* labels, int32_t labels_uniform, const float* self_cond, float* out,
+                        float* sym_err, void* ws, size_t ws_bytes, void* stream);
+
+/* ---- op-level entry points (each replaces one reference module's forward) ------------ */
+/* a8: PositionalEmbedding + map_layer0/1 (:507-513, :757-760) and every affine layer:
+ * c_noise [Bc] -> cond [Bc, cond_total]. */
+int swg_noise_embed(const swg_net* net, int32_t Bc, const float* c_noise, float* cond, void* ws, size_t ws_bytes,
+                    void* stream);
+/* a9 (+ self-cond concat :769-771, + c_in scaling precond.py:47): x [B,N,N], self_cond [B,N,N] or NULL,
+ * c_in [B] or NULL (=1), cond rows of stride cond_stride (0 = one row for the whole batch) -> tok [B, L, C0] */
+int swg_patch_embed_fwd(const swg_net* net, int32_t B, const float* x, const float* self_cond, const float* c_in,
+                        int32_t c_in_stride, const float* cond, int32_t cond_stride, float* tok, void* stream);
+/* a1 + a2 + first half of a3 (:238-272): x <- silu(shift + x(1+scale)); x <- x + Attn(LN1(x)) with the
+ * window partition / cyclic shift folded into addressing.  x_in, x_out [B, res*res, C] fp32. */
+int swg_wattn_fwd(const swg_block* blk, int32_t B, const float* x_in, const float* cond, int32_t cond_stride,
+                  float* x_out, void* ws, size_t ws_bytes, void* stream);
+/* a4 + LN2 + residual (:275): x_out = x_in + fc2(GELU(fc1(LN2(x_in)))) */
+int swg_ln_mlp_fwd(const swg_block* blk, int32_t B, const float* x_in, float* x_out, void* ws, size_t ws_bytes,
+                   void* stream);
+/* a5: [B, res*res, C] -> [B, res*res/4, 2C] */
+int swg_patch_merge_fwd(const swg_merge* m, int32_t B, const float* x_in, float* x_out, void* ws, size_t ws_bytes,
+                        void* stream);
+/* a6 incl. the concat of :743: x [B, res*res, Cin/2], skip [B, res*res, Cin/2] -> [B, 4*res*res, Cin/4] */
+int swg_patch_expand_fwd(const swg_breakup* u, int32_t B, const float* x, const float* skip, float* x_out, void* ws,
+                         size_t ws_bytes, void* stream);
+/* a10 tail + a11 + a13 epilogue: final LN, collapsed read-out, mask, (F+F^T)/2, then
+ * out = mask(c_skip*x + c_out*F); coef [B,4] = (c_skip, c_out, c_in, c_noise) or NULL (c_skip 0, c_out 1). */
+int swg_readout_sym_precond_fwd(const swg_net* net, int32_t B, const float* tok, const float* x,
+                                const float* node_flags, const float* coef, float* out, float* sym_err, void* ws,
+                                size_t ws_bytes, void* stream);
+
+/* ---- EDM Heun sampler updates (runner/mcmc_sampler/edm.py:168-217, shipped defaults) -- */
+/* :174-176  x_hat = mask(x + noise_coef * sym(raw)),  sym(raw) = triu(raw,1) + triu(raw,1)^T
+ * (utils/graph_utils.py:113-119).  All tensors [B,N,N] fp32. */
+int swg_heun_churn(int32_t B, int32_t N, const float* x, const float* raw_noise, const float* node_flags,
+                   float noise_coef, float* x_hat, void* stream);
+/* :188-193  d = mask((x_hat - mask(D))/t_hat); x_prime = x_hat + h*d (not masked); if last step
+ * (:197) callers use x_prime masked -> `mask_out` != 0.  d_cur is written when non-NULL. */
+int swg_heun_euler(int32_t B, int32_t N, const float* x_hat, const float* denoised, const float* node_flags,
+                   float t_hat, float h, int32_t mask_out, float* d_cur, float* x_prime, void* stream);
+/* :211-215  d' = (x_prime - D2)/t_prime; x_next = mask(x_hat + h*(0.5 d_cur + 0.5 d')) */
+int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_prime, const float* d_cur,
+                     const float* denoised2, const float* node_flags, float t_prime, float h, float* x_next,
+                     void* stream);
+/* utils/graph_utils.py:5-38 (in place) and :89-94 (acc += sum|a - a^T|, no host sync) */
+int swg_mask_adjs(int32_t B, int32_t N, float* a, const float* node_flags, void* stream);
+int swg_sym_check(int32_t B, int32_t N, const float* a, float* acc, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* SWINGNN_HIP_H */

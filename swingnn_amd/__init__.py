@@ -1,0 +1,14 @@
+"""MI355X-native SwinGNN denoiser hot path: drop-in ``SwinGNN``, ``Precond`` and ``EDMSampler`` whose
+arithmetic runs in hand-written gfx950 HIP kernels (libswingnn_hip.so, include/swingnn_hip.h).
+
+Importing this package loads the shared library and raises ImportError if it is missing:
+there is no CPU or PyTorch fallback.
+"""
+from . import _lib  # noqa: F401  (fails loudly when the HIP library is absent)
+from .swin_gnn import (SwinGNN, SwinTransformerBlock, WindowAttention, PatchMerging, PatchBreakup, PatchEmbed,
+                       BasicLayer, Mlp, PositionalEmbedding)
+from .precond import Precond
+from .edm_sampler import EDMSampler, GeneralSampler
+
+__all__ = ["SwinGNN", "SwinTransformerBlock", "WindowAttention", "PatchMerging", "PatchBreakup", "PatchEmbed",
+           "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler"]

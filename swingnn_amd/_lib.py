@@ -1,0 +1,105 @@
+"""ctypes binding of libswingnn_hip.so (include/swingnn_hip.h).
+
+The product path has no fallback: if the shared library is missing or does not load, importing
+this module raises, and so does every op.
+"""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libswingnn_hip.so")
+
+SWG_NOISE_EMB = 512
+ERRORS = {-1: "SWG_E_SHAPE", -2: "SWG_E_UNSUPPORTED", -3: "SWG_E_WORKSPACE", -4: "SWG_E_NULL"}
+
+_fp = C.c_void_p  # device pointers travel as void*
+
+
+class SwgLin(C.Structure):
+    _fields_ = [("w", _fp), ("b", _fp), ("N", C.c_int32), ("K", C.c_int32), ("Kp", C.c_int32)]
+
+
+class SwgLn(C.Structure):
+    _fields_ = [("g", _fp), ("b", _fp)]
+
+
+class SwgBlock(C.Structure):
+    _fields_ = [("C", C.c_int32), ("res", C.c_int32), ("win", C.c_int32), ("shift", C.c_int32),
+                ("heads", C.c_int32), ("cond_off", C.c_int32),
+                ("ln1", SwgLn), ("ln2", SwgLn),
+                ("qkv", SwgLin), ("proj", SwgLin), ("fc1", SwgLin), ("fc2", SwgLin),
+                ("rpb", _fp)]
+
+
+class SwgMerge(C.Structure):
+    _fields_ = [("C", C.c_int32), ("res", C.c_int32), ("ln", SwgLn), ("red", SwgLin)]
+
+
+class SwgBreakup(C.Structure):
+    _fields_ = [("Cin", C.c_int32), ("res", C.c_int32), ("pre", SwgLin), ("ln", SwgLn), ("post_ln", SwgLn),
+                ("post", SwgLin)]
+
+
+class SwgLayer(C.Structure):
+    _fields_ = [("n_blocks", C.c_int32), ("is_decoder", C.c_int32),
+                ("blocks", C.POINTER(SwgBlock)), ("down", C.POINTER(SwgMerge)), ("up", C.POINTER(SwgBreakup))]
+
+
+class SwgNet(C.Structure):
+    _fields_ = [("N", C.c_int32), ("p", C.c_int32), ("in_ch", C.c_int32), ("C0", C.c_int32),
+                ("n_layers", C.c_int32), ("self_cond", C.c_int32), ("cond_total", C.c_int32),
+                ("pe_cond_off", C.c_int32),
+                ("freqs", _fp), ("map0_w", _fp), ("map0_b", _fp), ("map1_w", _fp), ("map1_b", _fp),
+                ("aff_w", _fp), ("aff_b", _fp),
+                ("pe_w", _fp), ("pe_b", _fp), ("pe_ln", SwgLn),
+                ("layers", C.POINTER(SwgLayer)),
+                ("norm", SwgLn), ("ro_w", _fp), ("ro_b", C.c_float)]
+
+
+# every symbol include/swingnn_hip.h declares: name -> (restype, argtypes)
+_i32, _sz, _f = C.c_int32, C.c_size_t, C.c_float
+SYMBOLS = {
+    "swg_version": (C.c_int, []),
+    "swg_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),
+    "swg_precond_forward": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_noise_embed": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _sz, _fp]),
+    "swg_patch_embed_fwd": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _i32, _fp, _i32, _fp, _fp]),
+    "swg_wattn_fwd": (C.c_int, [C.POINTER(SwgBlock), _i32, _fp, _fp, _i32, _fp, _fp, _sz, _fp]),
+    "swg_ln_mlp_fwd": (C.c_int, [C.POINTER(SwgBlock), _i32, _fp, _fp, _fp, _sz, _fp]),
+    "swg_patch_merge_fwd": (C.c_int, [C.POINTER(SwgMerge), _i32, _fp, _fp, _fp, _sz, _fp]),
+    "swg_patch_expand_fwd": (C.c_int, [C.POINTER(SwgBreakup), _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_readout_sym_precond_fwd": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_heun_churn": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _f, _fp, _fp]),
+    "swg_heun_euler": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _f, _f, _i32, _fp, _fp, _fp]),
+    "swg_heun_correct": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp]),
+    "swg_mask_adjs": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
+    "swg_sym_check": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
+}
+
+
+def _load():
+    if not os.path.exists(LIB_PATH):
+        raise ImportError(
+            f"{LIB_PATH} is missing: build it with `make -C swingnn_amd/csrc` (or __graft_entry__.build()). "
+            "swingnn_amd has no CPU or PyTorch fallback.")
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in SYMBOLS.items():
+        fn = getattr(lib, name)  # AttributeError if the symbol is not exported
+        fn.restype = res
+        fn.argtypes = args
+    return lib
+
+
+lib = _load()
+
+
+class SwgError(RuntimeError):
+    pass
+
+
+def check(code: int, what: str):
+    if code == 0:
+        return
+    if code < 0:
+        raise SwgError(f"{what}: {ERRORS.get(code, code)}")
+    raise SwgError(f"{what}: hipError_t {code}")

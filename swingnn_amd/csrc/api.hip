@@ -1,0 +1,322 @@
+// extern "C" entry points of libswingnn_hip.so (declared in include/swingnn_hip.h) and the host-side
+// sequencing of one SwinGNN pass (model/swin_gnn/swin_gnn.py:729-779).  Nothing here allocates or
+// synchronises; every buffer is carved out of the caller's workspace.
+#include "common.h"
+
+namespace {
+
+struct Carver {
+  char* p;
+  size_t left;
+  bool ok;
+  Carver(void* ws, size_t bytes) : p((char*)ws), left(bytes), ok(ws != nullptr) {}
+  template <typename T>
+  T* take(size_t n) {
+    const size_t b = align256(n * sizeof(T));
+    if (!ok || b > left) { ok = false; return nullptr; }
+    T* r = (T*)p;
+    p += b;
+    left -= b;
+    return r;
+  }
+};
+
+inline int kp(int k) { return round_up(k, 32); }
+inline int ldq_of(int C) { return round_up(3 * C, 8); }
+
+// ---- scratch needs of each op (bytes) ----
+size_t ws_wattn(int T, int C) {
+  return align256((size_t)T * C * 4) + 2 * align256((size_t)T * kp(C) * 2) + align256((size_t)T * ldq_of(C) * 2);
+}
+size_t ws_mlp(int T, int C) { return align256((size_t)T * kp(C) * 2) + align256((size_t)T * kp(4 * C) * 2); }
+size_t ws_merge(int T, int C) { return align256((size_t)(T / 4) * kp(4 * C) * 2); }
+size_t ws_expand(int T, int Cin) {
+  return align256((size_t)T * kp(Cin) * 2) + align256((size_t)T * Cin * 4) + align256((size_t)4 * T * kp(Cin / 4) * 2);
+}
+size_t ws_embed(int Bc, int C0) { return align256((size_t)Bc * C0 * 4) + 2 * align256((size_t)Bc * SWG_NOISE_EMB * 4); }
+size_t ws_readout(int B, int N) { return align256((size_t)B * N * N * 4); }
+
+int check_lin(const swg_lin& l, int N, int K) {
+  if (!l.w) return SWG_E_NULL;
+  if (l.N != N || l.K != K || l.Kp != kp(K)) return SWG_E_SHAPE;
+  return 0;
+}
+
+int check_block(const swg_block* b) {
+  if (!b) return SWG_E_NULL;
+  if (b->C <= 0 || b->C % 4 || b->heads <= 0 || b->C % b->heads || b->win <= 0 || b->res % b->win) return SWG_E_SHAPE;
+  if (b->shift < 0 || b->shift >= b->win) return SWG_E_SHAPE;
+  if (!b->ln1.g || !b->ln1.b || !b->ln2.g || !b->ln2.b || !b->rpb) return SWG_E_NULL;
+  int r;
+  if ((r = check_lin(b->qkv, 3 * b->C, b->C))) return r;
+  if ((r = check_lin(b->proj, b->C, b->C))) return r;
+  if ((r = check_lin(b->fc1, 4 * b->C, b->C))) return r;
+  if ((r = check_lin(b->fc2, b->C, 4 * b->C))) return r;
+  return 0;
+}
+
+int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond, int cond_stride, float* x_out,
+               void* ws, size_t ws_bytes, hipStream_t s) {
+  int r = check_block(blk);
+  if (r) return r;
+  if (!x_in || !x_out || !cond) return SWG_E_NULL;
+  const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C), ldq = ldq_of(C);
+  Carver cv(ws, ws_bytes);
+  float* x1 = cv.take<float>((size_t)T * C);
+  bf16* xn = cv.take<bf16>((size_t)T * Cp);
+  bf16* o = cv.take<bf16>((size_t)T * Cp);
+  bf16* qkv = cv.take<bf16>((size_t)T * ldq);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  // x1 = silu(shift + x(1+scale)) (the shortcut, :240-242); xn = LN1(x1) in bf16
+  if ((r = launch_cond_ln(x_in, T, C, L, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, x1, xn, Cp, s))) return r;
+  GemmEpi e = {};
+  e.bias = blk->qkv.b; e.out_bf16 = qkv; e.ldo = ldq; e.n_store = 3 * C;
+  if ((r = launch_gemm(xn, Cp, (const bf16*)blk->qkv.w, T, 3 * C, Cp, e, s))) return r;
+  if ((r = launch_wattn_core(qkv, ldq, B, blk->res, blk->win, blk->shift, blk->heads, C, blk->rpb, o, Cp, s))) return r;
+  GemmEpi e2 = {};
+  e2.bias = blk->proj.b; e2.residual = x1; e2.ldr = C; e2.out_f32 = x_out; e2.ldo = C;
+  return launch_gemm(o, Cp, (const bf16*)blk->proj.w, T, C, Cp, e2, s);
+}
+
+int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void* ws, size_t ws_bytes, hipStream_t s) {
+  int r = check_block(blk);
+  if (r) return r;
+  if (!x_in || !x_out) return SWG_E_NULL;
+  const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C), Hp = kp(4 * C);
+  Carver cv(ws, ws_bytes);
+  bf16* xn = cv.take<bf16>((size_t)T * Cp);
+  bf16* hbuf = cv.take<bf16>((size_t)T * Hp);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  if ((r = launch_cond_ln(x_in, T, C, L, nullptr, 0, 0, blk->ln2.g, blk->ln2.b, nullptr, xn, Cp, s))) return r;
+  GemmEpi e = {};
+  e.bias = blk->fc1.b; e.act = 1; e.out_bf16 = hbuf; e.ldo = Hp; e.n_store = Hp;
+  if ((r = launch_gemm(xn, Cp, (const bf16*)blk->fc1.w, T, 4 * C, Cp, e, s))) return r;
+  GemmEpi e2 = {};
+  e2.bias = blk->fc2.b; e2.residual = x_in; e2.ldr = C; e2.out_f32 = x_out; e2.ldo = C;
+  return launch_gemm(hbuf, Hp, (const bf16*)blk->fc2.w, T, C, Hp, e2, s);
+}
+
+int merge_impl(const swg_merge* m, int B, const float* x_in, float* x_out, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!m || !x_in || !x_out || !m->ln.g || !m->ln.b) return SWG_E_NULL;
+  if (m->res % 2 || m->C % 4) return SWG_E_SHAPE;
+  int r;
+  if ((r = check_lin(m->red, 2 * m->C, 4 * m->C))) return r;
+  const int T4 = B * (m->res / 2) * (m->res / 2), Kp = kp(4 * m->C);
+  Carver cv(ws, ws_bytes);
+  bf16* xn = cv.take<bf16>((size_t)T4 * Kp);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  if ((r = launch_merge_ln(x_in, B, m->res, m->C, m->ln.g, m->ln.b, xn, Kp, s))) return r;
+  GemmEpi e = {};
+  e.out_f32 = x_out; e.ldo = 2 * m->C;
+  return launch_gemm(xn, Kp, (const bf16*)m->red.w, T4, 2 * m->C, Kp, e, s);
+}
+
+int expand_impl(const swg_breakup* u, int B, const float* x, const float* skip, float* x_out, void* ws, size_t ws_bytes,
+                hipStream_t s) {
+  if (!u || !x || !skip || !x_out || !u->ln.g || !u->ln.b || !u->post_ln.g || !u->post_ln.b) return SWG_E_NULL;
+  if (u->Cin % 16) return SWG_E_SHAPE;
+  const int Cin = u->Cin, Co = Cin / 4, T = B * u->res * u->res, Kp = kp(Cin), Cop = kp(Co);
+  int r;
+  if ((r = check_lin(u->pre, Cin, Cin))) return r;
+  if ((r = check_lin(u->post, Co, Co))) return r;
+  Carver cv(ws, ws_bytes);
+  bf16* cat = cv.take<bf16>((size_t)T * Kp);
+  float* y = cv.take<float>((size_t)T * Cin);
+  bf16* sc = cv.take<bf16>((size_t)4 * T * Cop);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  if ((r = launch_concat_cast(x, skip, T, Cin / 2, cat, Kp, s))) return r;  // torch.cat([x, skip], -1), :743
+  GemmEpi e = {};
+  e.out_f32 = y; e.ldo = Cin;
+  if ((r = launch_gemm(cat, Kp, (const bf16*)u->pre.w, T, Cin, Kp, e, s))) return r;
+  if ((r = launch_ln_f32(y, T, Cin, u->ln.g, u->ln.b, y, s))) return r;  // in place: a row is read then written by its own lanes
+  if ((r = launch_breakup_ln(y, B, u->res, Co, u->post_ln.g, u->post_ln.b, sc, Cop, s))) return r;
+  GemmEpi e2 = {};
+  e2.out_f32 = x_out; e2.ldo = Co;
+  return launch_gemm(sc, Cop, (const bf16*)u->post.w, 4 * T, Co, Cop, e2, s);
+}
+
+int embed_impl(const swg_net* net, int Bc, const float* c_noise, float* cond, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!net || !c_noise || !cond || !net->freqs || !net->map0_w || !net->map1_w || !net->aff_w) return SWG_E_NULL;
+  if (net->C0 % 4) return SWG_E_UNSUPPORTED;
+  Carver cv(ws, ws_bytes);
+  float* e0 = cv.take<float>((size_t)Bc * net->C0);
+  float* e1 = cv.take<float>((size_t)Bc * SWG_NOISE_EMB);
+  float* e2 = cv.take<float>((size_t)Bc * SWG_NOISE_EMB);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  int r;
+  if ((r = launch_pos_embed(c_noise, Bc, net->freqs, net->C0 / 2, e0, s))) return r;
+  if ((r = launch_gemv_rows(net->map0_w, net->map0_b, e0, Bc, SWG_NOISE_EMB, net->C0, 1, e1, s))) return r;
+  if ((r = launch_gemv_rows(net->map1_w, net->map1_b, e1, Bc, SWG_NOISE_EMB, SWG_NOISE_EMB, 1, e2, s))) return r;
+  return launch_gemv_rows(net->aff_w, net->aff_b, e2, Bc, net->cond_total, SWG_NOISE_EMB, 0, cond, s);
+}
+
+int readout_impl(const swg_net* net, int B, const float* tok, const float* x, const float* flags, const float* coef,
+                 float* out, float* sym_err, void* ws, size_t ws_bytes, hipStream_t s) {
+  if (!net || !tok || !flags || !out || !net->ro_w || !net->norm.g || !net->norm.b) return SWG_E_NULL;
+  Carver cv(ws, ws_bytes);
+  float* F = cv.take<float>((size_t)B * net->N * net->N);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  int r;
+  if ((r = launch_final_readout(net, B, tok, F, s))) return r;
+  return launch_sym_precond(B, net->N, F, x, flags, coef, out, sym_err, s);
+}
+
+// maximum scratch over all ops of one pass + persistent buffers
+struct NetPlan {
+  size_t persistent, scratch;
+  size_t maxTC;  // floats of the widest residual-stream tensor
+};
+
+int plan_net(const swg_net* net, int B, NetPlan* pl) {
+  if (!net || !net->layers) return SWG_E_NULL;
+  if (net->N <= 0 || net->p <= 0 || net->N % net->p || net->n_layers <= 0 || net->n_layers % 2) return SWG_E_SHAPE;
+  const int hp = net->N / net->p;
+  size_t scratch = ws_embed(B, net->C0);
+  scratch = max(scratch, ws_readout(B, net->N));
+  size_t maxTC = (size_t)B * hp * hp * net->C0;
+  size_t skips = 0;
+  const int S = net->n_layers / 2;
+  for (int li = 0; li < net->n_layers; ++li) {
+    const swg_layer& ly = net->layers[li];
+    if (ly.up) {
+      const int T = B * ly.up->res * ly.up->res;
+      scratch = max(scratch, ws_expand(T, ly.up->Cin));
+      maxTC = max(maxTC, (size_t)4 * T * (ly.up->Cin / 4));
+    }
+    for (int j = 0; j < ly.n_blocks; ++j) {
+      const swg_block& b = ly.blocks[j];
+      const int T = B * b.res * b.res;
+      scratch = max(scratch, max(ws_wattn(T, b.C), ws_mlp(T, b.C)));
+      maxTC = max(maxTC, (size_t)T * b.C);
+    }
+    if (ly.down) {
+      const int T = B * ly.down->res * ly.down->res;
+      scratch = max(scratch, ws_merge(T, ly.down->C));
+      if (li < S) skips += align256((size_t)(T / 4) * 2 * ly.down->C * 4);
+    }
+  }
+  pl->maxTC = maxTC;
+  pl->scratch = scratch;
+  pl->persistent = align256((size_t)B * 4 * 4) + align256((size_t)B * 4) + align256((size_t)B * net->cond_total * 4) +
+                   align256(maxTC * 4) + skips;
+  return 0;
+}
+
+}  // namespace
+
+extern "C" {
+
+int swg_version(void) { return 1; }
+
+size_t swg_workspace_bytes(const swg_net* net, int32_t B) {
+  NetPlan pl;
+  if (B <= 0 || plan_net(net, B, &pl)) return 0;
+  return pl.persistent + pl.scratch + 4096;
+}
+
+int swg_noise_embed(const swg_net* net, int32_t Bc, const float* c_noise, float* cond, void* ws, size_t ws_bytes,
+                    void* stream) {
+  if (Bc <= 0) return SWG_E_SHAPE;
+  return embed_impl(net, Bc, c_noise, cond, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int swg_patch_embed_fwd(const swg_net* net, int32_t B, const float* x, const float* self_cond, const float* c_in,
+                        int32_t c_in_stride, const float* cond, int32_t cond_stride, float* tok, void* stream) {
+  if (!net || !x || !cond || !tok || !net->pe_w || !net->pe_b || !net->pe_ln.g || !net->pe_ln.b) return SWG_E_NULL;
+  if (B <= 0) return SWG_E_SHAPE;
+  return launch_patch_embed(net, B, x, self_cond, c_in, c_in_stride, cond, cond_stride, tok, (hipStream_t)stream);
+}
+
+int swg_wattn_fwd(const swg_block* blk, int32_t B, const float* x_in, const float* cond, int32_t cond_stride,
+                  float* x_out, void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0) return SWG_E_SHAPE;
+  return wattn_impl(blk, B, x_in, cond, cond_stride, x_out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int swg_ln_mlp_fwd(const swg_block* blk, int32_t B, const float* x_in, float* x_out, void* ws, size_t ws_bytes,
+                   void* stream) {
+  if (B <= 0) return SWG_E_SHAPE;
+  return mlp_impl(blk, B, x_in, x_out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int swg_patch_merge_fwd(const swg_merge* m, int32_t B, const float* x_in, float* x_out, void* ws, size_t ws_bytes,
+                        void* stream) {
+  if (B <= 0) return SWG_E_SHAPE;
+  return merge_impl(m, B, x_in, x_out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int swg_patch_expand_fwd(const swg_breakup* u, int32_t B, const float* x, const float* skip, float* x_out, void* ws,
+                         size_t ws_bytes, void* stream) {
+  if (B <= 0) return SWG_E_SHAPE;
+  return expand_impl(u, B, x, skip, x_out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int swg_readout_sym_precond_fwd(const swg_net* net, int32_t B, const float* tok, const float* x,
+                                const float* node_flags, const float* coef, float* out, float* sym_err, void* ws,
+                                size_t ws_bytes, void* stream) {
+  if (B <= 0) return SWG_E_SHAPE;
+  if (coef && !x) return SWG_E_NULL;
+  return readout_impl(net, B, tok, x, node_flags, coef, out, sym_err, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float* x, const float* node_flags,
+                        const float* labels, int32_t labels_uniform, const float* self_cond, float* out,
+                        float* sym_err, void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!net || !x || !node_flags || !labels || !out) return SWG_E_NULL;
+  if (B <= 0 || (mode != 0 && mode != 1)) return SWG_E_SHAPE;
+  NetPlan pl;
+  int r = plan_net(net, B, &pl);
+  if (r) return r;
+  if (ws_bytes < pl.persistent + pl.scratch) return SWG_E_WORKSPACE;
+  const int S = net->n_layers / 2;
+  if (S > 8) return SWG_E_UNSUPPORTED;
+
+  Carver cv(ws, ws_bytes);
+  float* coef = cv.take<float>((size_t)B * 4);
+  float* cnoise = cv.take<float>((size_t)B);
+  const int Bc = labels_uniform ? 1 : B;
+  const int cstride = labels_uniform ? 0 : net->cond_total;
+  float* cond = cv.take<float>((size_t)B * net->cond_total);
+  float* A = cv.take<float>(pl.maxTC);
+  float* skips[8] = {};
+  for (int li = 0; li < S; ++li) {
+    const swg_layer& ly = net->layers[li];
+    if (ly.down) {
+      const int T = B * ly.down->res * ly.down->res;
+      skips[li] = cv.take<float>((size_t)(T / 4) * 2 * ly.down->C);
+    }
+  }
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  void* sw = cv.p;
+  const size_t sb = cv.left;
+
+  if ((r = launch_edm_coef(labels, B, labels_uniform, mode, coef, cnoise, s))) return r;
+  if ((r = embed_impl(net, Bc, cnoise, cond, sw, sb, s))) return r;
+  if ((r = launch_patch_embed(net, B, x, self_cond, coef + 2, 4, cond, cstride, A, s))) return r;
+
+  const float* cur = A;
+  for (int li = 0; li < net->n_layers; ++li) {
+    const swg_layer& ly = net->layers[li];
+    if (ly.up) {
+      const int si = net->n_layers - 1 - li;  // decoder layer i pops skips[S-1-i], :743
+      if (si < 0 || si >= S || !skips[si]) return SWG_E_SHAPE;
+      if ((r = expand_impl(ly.up, B, cur, skips[si], A, sw, sb, s))) return r;
+      cur = A;
+    }
+    for (int j = 0; j < ly.n_blocks; ++j) {
+      const swg_block* blk = &ly.blocks[j];
+      if ((r = wattn_impl(blk, B, cur, cond, cstride, A, sw, sb, s))) return r;
+      if ((r = mlp_impl(blk, B, A, A, sw, sb, s))) return r;
+      cur = A;
+    }
+    if (ly.down) {
+      if (li >= S) return SWG_E_SHAPE;
+      if ((r = merge_impl(ly.down, B, cur, skips[li], sw, sb, s))) return r;
+      cur = skips[li];
+    }
+  }
+  return readout_impl(net, B, cur, x, node_flags, coef, out, sym_err, sw, sb, s);
+}
+
+}  // extern "C"

@@ -1,0 +1,107 @@
+// Shared device helpers for the gfx950 SwinGNN kernels.
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/swingnn_hip.h"
+
+typedef __bf16 bf16;
+typedef __attribute__((ext_vector_type(8))) __bf16 bf16x8;
+typedef __attribute__((ext_vector_type(4))) __bf16 bf16x4;
+typedef __attribute__((ext_vector_type(4))) float f32x4;
+
+#define SWG_LAUNCH_CHECK()                         \
+  do {                                             \
+    hipError_t e__ = hipGetLastError();            \
+    if (e__ != hipSuccess) return (int)e__;        \
+  } while (0)
+
+static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
+static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
+static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+
+__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// nn.GELU() exact erf form (model/swin_gnn/swin_gnn.py:10,15)
+__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f)); }
+
+// sum over a group of LANES consecutive lanes (LANES power of two <= 64)
+template <int LANES>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+  return v;
+}
+
+__device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
+  bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
+  return *reinterpret_cast<uint2*>(&v);
+}
+
+// ---- row-kernel launch geometry: a row of `chunks` float4 is handled by LANES lanes x V chunks ----
+struct RowGeom {
+  int lanes, v;
+};
+static inline RowGeom row_geom(int chunks) {
+  RowGeom g;
+  int lanes = 4;
+  while (lanes < 64 && cdiv(chunks, lanes) > 3) lanes *= 2;
+  g.lanes = lanes;
+  g.v = cdiv(chunks, lanes);
+  return g;
+}
+
+// dispatch on (lanes, v); V in {1,2,3} for lanes < 64, {1,2,3,4,6,8} for lanes == 64
+#define SWG_ROW_DISPATCH(G, CALL)                                                       \
+  do {                                                                                  \
+    const int L__ = (G).lanes, V__ = (G).v;                                             \
+    if (L__ == 4 && V__ == 1) { CALL(4, 1); }                                           \
+    else if (L__ == 4 && V__ == 2) { CALL(4, 2); }                                      \
+    else if (L__ == 4 && V__ == 3) { CALL(4, 3); }                                      \
+    else if (L__ == 8 && V__ == 2) { CALL(8, 2); }                                      \
+    else if (L__ == 8 && V__ == 3) { CALL(8, 3); }                                      \
+    else if (L__ == 16 && V__ == 2) { CALL(16, 2); }                                    \
+    else if (L__ == 16 && V__ == 3) { CALL(16, 3); }                                    \
+    else if (L__ == 32 && V__ == 2) { CALL(32, 2); }                                    \
+    else if (L__ == 32 && V__ == 3) { CALL(32, 3); }                                    \
+    else if (L__ == 64 && V__ == 2) { CALL(64, 2); }                                    \
+    else if (L__ == 64 && V__ == 3) { CALL(64, 3); }                                    \
+    else if (L__ == 64 && V__ == 4) { CALL(64, 4); }                                    \
+    else if (L__ == 64 && (V__ == 5 || V__ == 6)) { CALL(64, 6); }                      \
+    else if (L__ == 64 && (V__ == 7 || V__ == 8)) { CALL(64, 8); }                      \
+    else return SWG_E_UNSUPPORTED;                                                      \
+  } while (0)
+
+// ---- internal launchers (defined in the .hip files, used by api.hip) ---------------------------
+// rowops.hip
+int launch_cond_ln(const float* x, int rows, int C, int L, const float* cond, int cond_stride, int cond_off,
+                   const float* g, const float* b, float* x1, bf16* xn, int ldn, hipStream_t s);
+int launch_merge_ln(const float* x, int B, int res, int C, const float* g, const float* b, bf16* xn, int ldn,
+                    hipStream_t s);
+int launch_concat_cast(const float* a, const float* b, int rows, int Ch, bf16* out, int ldo, hipStream_t s);
+int launch_ln_f32(const float* x, int rows, int C, const float* g, const float* b, float* y, hipStream_t s);
+int launch_breakup_ln(const float* y, int B, int res, int Co, const float* g, const float* b, bf16* out, int ldo,
+                      hipStream_t s);
+int launch_gemv_rows(const float* W, const float* bias, const float* x, int Bx, int N, int K, int act, float* out,
+                     hipStream_t s);
+int launch_pos_embed(const float* labels, int Bc, const float* freqs, int nf, float* out, hipStream_t s);
+int launch_edm_coef(const float* labels, int B, int uniform, int mode, float* coef, float* c_noise, hipStream_t s);
+int launch_patch_embed(const swg_net* net, int B, const float* x, const float* sc, const float* c_in, int c_in_stride,
+                       const float* cond, int cond_stride, float* tok, hipStream_t s);
+int launch_final_readout(const swg_net* net, int B, const float* tok, float* F, hipStream_t s);
+int launch_sym_precond(int B, int N, const float* F, const float* x, const float* flags, const float* coef, float* out,
+                       float* sym_err, hipStream_t s);
+// gemm.hip : out[M,N] = A[M,Kp] @ W[N,Kp]^T (+bias)(gelu)(+residual)
+struct GemmEpi {
+  const float* bias;      // [N] or null
+  const float* residual;  // fp32 [M, ldr] or null
+  int ldr;
+  int act;                // 0 none, 1 gelu
+  float* out_f32;         // fp32 [M, ldo] or null
+  bf16* out_bf16;         // bf16 [M, ldo] or null; columns [N, n_store) are written as zero
+  int ldo;
+  int n_store;
+};
+int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, const GemmEpi& e, hipStream_t s);
+// wattn.hip : window attention core on a qkv buffer
+int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shift, int heads, int C, const float* rpb,
+                      bf16* o, int ldo, hipStream_t s);

@@ -1,0 +1,161 @@
+// bf16 MFMA GEMM for the token-wise linear layers:  out[M,N] = A[M,Kp] @ W[N,Kp]^T  (nn.Linear layout).
+//
+// gfx950 design notes
+//  * v_mfma_f32_16x16x32_bf16 with SWAPPED operands: the MFMA "A" operand is a W tile (rows = output
+//    features n) and the "B" operand is an activation tile (rows = tokens m).  The accumulator then has the
+//    token on the lane (m = lane & 15) and four CONSECUTIVE output features in its four registers
+//    (n = 4*(lane>>4) + r), so the epilogue loads bias / residual and stores results as 16-byte (fp32) or
+//    8-byte (bf16) vectors with no cross-lane movement.
+//  * 128 x 128 block tile, 4 waves as 2(m) x 2(n), each wave 64 x 64 = 4 x 4 MFMA tiles (64 accumulator VGPRs).
+//  * Operands go global -> registers -> LDS (ds_write_b128) with an XOR swizzle on the 16-byte chunk index so
+//    that the ds_read_b128 fragment reads are bank-conflict free; LDS is double buffered and the global loads
+//    of tile k+1 are in flight while tile k is multiplied (one barrier per K tile).
+//  * blockIdx is remapped so that consecutive logical tiles (which share the activation row panel) land on
+//    the same XCD and hit its L2.
+#include "common.h"
+
+namespace {
+
+constexpr int BM = 128, BN = 128;
+
+template <int BK>
+struct Swz {
+  static constexpr int CH = BK / 8;  // 16-byte chunks per LDS row
+  __device__ static __forceinline__ int chunk(int row, int ch) {
+    if (BK == 64) return ch ^ (row & 7);
+    return ch ^ ((-(row >> 2)) & 3);  // BK == 32
+  }
+};
+
+// bijective XCD remap (8 XCDs, round-robin dispatch): logical tile id from hardware block id
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  const int q = nwg >> 3, r = nwg & 7;
+  const int xcd = bid & 7, slot = bid >> 3;
+  const int start = (xcd < r) ? xcd * (q + 1) : r * (q + 1) + (xcd - r) * q;
+  return start + slot;
+}
+
+template <int BK>
+__global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W,
+                                                 int M, int N, int Kp, GemmEpi e, int tiles_n) {
+  constexpr int CH = Swz<BK>::CH;
+  constexpr int LD_PER_THR = (BM * CH) / 256;  // 16-byte chunks per thread per operand tile
+  constexpr int KSTEPS = BK / 32;
+  __shared__ __attribute__((aligned(16))) bf16 sX[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 sW[2][BN * BK];
+
+  const int nwg = gridDim.x;
+  const int tile = xcd_remap(blockIdx.x, nwg);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;  // n fastest: neighbours share the X panel
+  const int m0 = tm * BM, n0 = tn * BN;
+
+  const int tid = threadIdx.x;
+  const int lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // global -> register staging
+  uint4 rx[LD_PER_THR], rw[LD_PER_THR];
+  auto g_load = [&](int kt) {
+#pragma unroll
+    for (int i = 0; i < LD_PER_THR; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / CH, ch = id - row * CH;
+      const int gm = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);
+      rx[i] = *reinterpret_cast<const uint4*>(A + (size_t)gm * lda + kt * BK + ch * 8);
+      rw[i] = *reinterpret_cast<const uint4*>(W + (size_t)gn * Kp + kt * BK + ch * 8);
+    }
+  };
+  auto s_store = [&](int buf) {
+#pragma unroll
+    for (int i = 0; i < LD_PER_THR; ++i) {
+      const int id = tid + i * 256;
+      const int row = id / CH, ch = id - row * CH;
+      const int off = row * BK + Swz<BK>::chunk(row, ch) * 8;
+      *reinterpret_cast<uint4*>(&sX[buf][off]) = rx[i];
+      *reinterpret_cast<uint4*>(&sW[buf][off]) = rw[i];
+    }
+  };
+
+  f32x4 acc[4][4];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  const int nk = Kp / BK;
+  g_load(0);
+  s_store(0);
+  __syncthreads();
+  for (int kt = 0; kt < nk; ++kt) {
+    const int buf = kt & 1;
+    if (kt + 1 < nk) g_load(kt + 1);
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      bf16x8 fw[4], fx[4];
+#pragma unroll
+      for (int t = 0; t < 4; ++t) {
+        const int rw_ = wn * 64 + t * 16 + l15;
+        const int rx_ = wm * 64 + t * 16 + l15;
+        fw[t] = *reinterpret_cast<const bf16x8*>(&sW[buf][rw_ * BK + Swz<BK>::chunk(rw_, ks * 4 + lg) * 8]);
+        fx[t] = *reinterpret_cast<const bf16x8*>(&sX[buf][rx_ * BK + Swz<BK>::chunk(rx_, ks * 4 + lg) * 8]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 4; ++mt)
+          acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[nt][mt], 0, 0, 0);
+    }
+    if (kt + 1 < nk) s_store(buf ^ 1);
+    __syncthreads();
+  }
+
+  // epilogue: lane owns token m = ... + l15 and features n = ... + 4*lg + {0..3}
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt) {
+    const int m = m0 + wm * 64 + mt * 16 + l15;
+    if (m >= M) continue;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + 4 * lg;
+      if (n >= e.n_store) continue;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        v = make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+        if (e.bias) {
+          const float4 bb = *reinterpret_cast<const float4*>(e.bias + n);
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (e.act == 1) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+        if (e.residual) {
+          const float4 rr = *reinterpret_cast<const float4*>(e.residual + (size_t)m * e.ldr + n);
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+      }
+      if (e.out_f32) {
+        if (n < N) *reinterpret_cast<float4*>(e.out_f32 + (size_t)m * e.ldo + n) = v;
+      } else {
+        *reinterpret_cast<uint2*>(e.out_bf16 + (size_t)m * e.ldo + n) = pack_bf16x4(v.x, v.y, v.z, v.w);
+      }
+    }
+  }
+}
+
+}  // namespace
+
+int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, const GemmEpi& e, hipStream_t s) {
+  if (M <= 0) return 0;
+  if (Kp % 32 || lda % 8 || lda < Kp || N % 4 || e.ldo % 4 || (e.residual && e.ldr % 4)) return SWG_E_SHAPE;
+  if (!e.out_f32 && !e.out_bf16) return SWG_E_NULL;
+  GemmEpi ee = e;
+  if (ee.out_f32) ee.n_store = N;
+  if (ee.n_store < N || ee.n_store > ee.ldo || ee.n_store % 4) return SWG_E_SHAPE;
+  const int tiles_m = cdiv(M, BM), tiles_n = cdiv(ee.n_store, BN);
+  const int nwg = tiles_m * tiles_n;
+  if (Kp % 64 == 0)
+    hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
+  else
+    hipLaunchKernelGGL(k_gemm_nt<32>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}

@@ -1,0 +1,682 @@
+// Memory-bound kernels of the SwinGNN denoiser path (gfx950): conditioning + LayerNorm prologues,
+// patch merge / breakup re-layouts, patch embedding, noise embedding, read-out + symmetrise +
+// preconditioning epilogue, and the EDM Heun updates.  All of them are HBM-bound: rows are read
+// once as float4 by a lane group, statistics are reduced with wavefront shuffles, bf16 is only a
+// storage format for the following MFMA GEMMs.
+#include "common.h"
+
+// ------------------------------------------------------------------------------------------------
+// Generic row kernel: LANES lanes own one output row, V float4 chunks per lane.
+// ------------------------------------------------------------------------------------------------
+enum RowMode { ROW_COND_LN = 0, ROW_MERGE_LN = 1, ROW_CONCAT = 2, ROW_LN_F32 = 3, ROW_BREAKUP_LN = 4 };
+
+struct RowArgs {
+  const float* x;   // primary source
+  const float* x2;  // second source (concat)
+  int rows;         // output rows
+  int C;            // logical row width (floats) over which LN runs
+  int L;            // tokens per graph (cond row lookup)
+  int res;          // spatial side (merge: input res; breakup: input res)
+  int Csrc;         // merge: source token width; concat: width of each half; breakup: Co
+  const float* cond;
+  int cond_stride, cond_off;
+  const float* g;
+  const float* b;
+  float* out_f32;   // optional fp32 output (row stride C)
+  bf16* out_bf16;   // optional bf16 output (row stride ldo, zero padded)
+  int ldo;
+};
+
+template <int LANES, int V, int MODE>
+__global__ __launch_bounds__(256) void k_row(RowArgs a) {
+  constexpr int RPB = 256 / LANES;
+  const int row = blockIdx.x * RPB + (int)threadIdx.x / LANES;
+  const int g = threadIdx.x % LANES;
+  if (row >= a.rows) return;  // whole lane group leaves together
+  const int nch = a.C >> 2;
+
+  // ---- source addressing ----
+  float4 v[V];
+  int src_tok = row;  // MERGE recomputes per chunk
+  int b_img = 0, Y = 0, X = 0;
+  if (MODE == ROW_MERGE_LN) {
+    const int r2 = a.res >> 1;
+    b_img = row / (r2 * r2);
+    const int rem = row - b_img * r2 * r2;
+    Y = rem / r2;
+    X = rem - Y * r2;
+  }
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = g + i * LANES;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nch) {
+      const float* p;
+      if (MODE == ROW_MERGE_LN) {
+        const int cs = a.Csrc >> 2;
+        const int k = c / cs, cc = c - k * cs;
+        const int dy = k & 1, dx = k >> 1;  // (0,0),(1,0),(0,1),(1,1): swin_gnn.py:325-329
+        src_tok = b_img * a.res * a.res + (2 * Y + dy) * a.res + (2 * X + dx);
+        p = a.x + (size_t)src_tok * a.Csrc + 4 * cc;
+      } else if (MODE == ROW_CONCAT) {
+        const int cs = a.Csrc >> 2;
+        p = (c < cs) ? a.x + (size_t)row * a.Csrc + 4 * c : a.x2 + (size_t)row * a.Csrc + 4 * (c - cs);
+      } else {
+        p = a.x + (size_t)row * a.C + 4 * c;  // BREAKUP_LN: input viewed as [4T, Co] contiguous rows
+      }
+      v[i] = *reinterpret_cast<const float4*>(p);
+    }
+  }
+
+  // ---- noise conditioning: x <- silu(shift + x*(scale+1)), swin_gnn.py:238-240 ----
+  if (MODE == ROW_COND_LN && a.cond != nullptr) {
+    const float* crow = a.cond + (size_t)(row / a.L) * a.cond_stride + a.cond_off;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = g + i * LANES;
+      if (c < nch) {
+        const float4 sc = *reinterpret_cast<const float4*>(crow + 4 * c);
+        const float4 sh = *reinterpret_cast<const float4*>(crow + a.C + 4 * c);
+        v[i].x = silu_f(sh.x + v[i].x * (sc.x + 1.f));
+        v[i].y = silu_f(sh.y + v[i].y * (sc.y + 1.f));
+        v[i].z = silu_f(sh.z + v[i].z * (sc.z + 1.f));
+        v[i].w = silu_f(sh.w + v[i].w * (sc.w + 1.f));
+        if (a.out_f32) *reinterpret_cast<float4*>(a.out_f32 + (size_t)row * a.C + 4 * c) = v[i];
+      }
+    }
+  }
+
+  // ---- LayerNorm statistics (biased variance, eps 1e-5) ----
+  if (MODE != ROW_CONCAT) {
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    const float mean = group_sum<LANES>(s) / (float)a.C;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = g + i * LANES;
+      if (c < nch) {
+        const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+        q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+      }
+    }
+    const float rstd = 1.0f / sqrtf(group_sum<LANES>(q) / (float)a.C + 1e-5f);
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = g + i * LANES;
+      if (c < nch) {
+        const float4 gg = *reinterpret_cast<const float4*>(a.g + 4 * c);
+        const float4 bb = *reinterpret_cast<const float4*>(a.b + 4 * c);
+        v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
+        v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
+        v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
+        v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
+      }
+    }
+  }
+
+  // ---- destination ----
+  int drow = row;
+  if (MODE == ROW_BREAKUP_LN) {
+    // input row = 4*t + k, t = (b, y, x) on the res grid; chunk k goes to (2y+dy, 2x+dx): swin_gnn.py:389-397
+    const int t = row >> 2, k = row & 3;
+    const int bi = t / (a.res * a.res);
+    const int rem = t - bi * a.res * a.res;
+    const int y = rem / a.res, x = rem - y * a.res;
+    const int dy = k & 1, dx = k >> 1;
+    drow = bi * 4 * a.res * a.res + (2 * y + dy) * 2 * a.res + (2 * x + dx);
+  }
+  if (MODE == ROW_LN_F32) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = g + i * LANES;
+      if (c < nch) *reinterpret_cast<float4*>(a.out_f32 + (size_t)drow * a.C + 4 * c) = v[i];
+    }
+  } else {
+    const int nst = a.ldo >> 2;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = g + i * LANES;
+      if (c < nst)  // chunks in [nch, nst) are the zero K-padding of the following GEMM
+        *reinterpret_cast<uint2*>(a.out_bf16 + (size_t)drow * a.ldo + 4 * c) = pack_bf16x4(v[i].x, v[i].y, v[i].z, v[i].w);
+    }
+  }
+}
+
+template <int MODE>
+static int launch_row(const RowArgs& a, int chunks, hipStream_t s) {
+  if (a.rows <= 0) return 0;
+  if (a.C % 4) return SWG_E_SHAPE;
+  RowGeom geo = row_geom(chunks);
+#define CALL(LN, VV)                                                                            \
+  hipLaunchKernelGGL((k_row<LN, VV, MODE>), dim3(cdiv(a.rows, 256 / LN)), dim3(256), 0, s, a)
+  SWG_ROW_DISPATCH(geo, CALL);
+#undef CALL
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cond_ln(const float* x, int rows, int C, int L, const float* cond, int cond_stride, int cond_off,
+                   const float* g, const float* b, float* x1, bf16* xn, int ldn, hipStream_t s) {
+  RowArgs a = {};
+  a.x = x; a.rows = rows; a.C = C; a.L = L; a.cond = cond; a.cond_stride = cond_stride; a.cond_off = cond_off;
+  a.g = g; a.b = b; a.out_f32 = x1; a.out_bf16 = xn; a.ldo = ldn;
+  return launch_row<ROW_COND_LN>(a, ldn / 4, s);
+}
+
+int launch_merge_ln(const float* x, int B, int res, int C, const float* g, const float* b, bf16* xn, int ldn,
+                    hipStream_t s) {
+  RowArgs a = {};
+  a.x = x; a.rows = B * (res / 2) * (res / 2); a.C = 4 * C; a.res = res; a.Csrc = C; a.g = g; a.b = b;
+  a.out_bf16 = xn; a.ldo = ldn;
+  return launch_row<ROW_MERGE_LN>(a, ldn / 4, s);
+}
+
+int launch_concat_cast(const float* xa, const float* xb, int rows, int Ch, bf16* out, int ldo, hipStream_t s) {
+  RowArgs a = {};
+  a.x = xa; a.x2 = xb; a.rows = rows; a.C = 2 * Ch; a.Csrc = Ch; a.out_bf16 = out; a.ldo = ldo;
+  return launch_row<ROW_CONCAT>(a, ldo / 4, s);
+}
+
+int launch_ln_f32(const float* x, int rows, int C, const float* g, const float* b, float* y, hipStream_t s) {
+  RowArgs a = {};
+  a.x = x; a.rows = rows; a.C = C; a.g = g; a.b = b; a.out_f32 = y;
+  return launch_row<ROW_LN_F32>(a, C / 4, s);
+}
+
+int launch_breakup_ln(const float* y, int B, int res, int Co, const float* g, const float* b, bf16* out, int ldo,
+                      hipStream_t s) {
+  RowArgs a = {};
+  a.x = y; a.rows = 4 * B * res * res; a.C = Co; a.res = res; a.g = g; a.b = b; a.out_bf16 = out; a.ldo = ldo;
+  return launch_row<ROW_BREAKUP_LN>(a, ldo / 4, s);
+}
+
+// ------------------------------------------------------------------------------------------------
+// Noise embedding (swin_gnn.py:507-513, 757-760) and the stacked affine layers: three small GEMVs.
+// One wavefront per output feature; the weight row stays in registers while the batch is swept.
+// ------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ W, const float* __restrict__ bias,
+                                                   const float* __restrict__ x, int Bx, int N, int K, int act,
+                                                   float* __restrict__ out) {
+  const int n = blockIdx.x * 4 + (threadIdx.x >> 6);
+  const int lane = threadIdx.x & 63;
+  if (n >= N) return;
+  const int kch = K >> 2;
+  float4 w0 = make_float4(0.f, 0.f, 0.f, 0.f), w1 = w0;
+  if (lane < kch) w0 = *reinterpret_cast<const float4*>(W + (size_t)n * K + 4 * lane);
+  if (lane + 64 < kch) w1 = *reinterpret_cast<const float4*>(W + (size_t)n * K + 4 * (lane + 64));
+  const float bn = bias ? bias[n] : 0.f;
+  for (int b = 0; b < Bx; ++b) {
+    float acc = 0.f;
+    if (lane < kch) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)b * K + 4 * lane);
+      acc += (w0.x * xv.x + w0.y * xv.y) + (w0.z * xv.z + w0.w * xv.w);
+    }
+    if (lane + 64 < kch) {
+      const float4 xv = *reinterpret_cast<const float4*>(x + (size_t)b * K + 4 * (lane + 64));
+      acc += (w1.x * xv.x + w1.y * xv.y) + (w1.z * xv.z + w1.w * xv.w);
+    }
+    acc = group_sum<64>(acc) + bn;
+    if (act == 1) acc = silu_f(acc);
+    if (lane == 0) out[(size_t)b * N + n] = acc;
+  }
+}
+
+int launch_gemv_rows(const float* W, const float* bias, const float* x, int Bx, int N, int K, int act, float* out,
+                     hipStream_t s) {
+  if (K % 4 || K > 512) return SWG_E_UNSUPPORTED;
+  hipLaunchKernelGGL(k_gemv_rows, dim3(cdiv(N, 4)), dim3(256), 0, s, W, bias, x, Bx, N, K, act, out);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+__global__ void k_pos_embed(const float* __restrict__ labels, int Bc, const float* __restrict__ freqs, int nf,
+                            float* __restrict__ out) {
+  const int i = blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= Bc * nf) return;
+  const int b = i / nf, k = i - b * nf;
+  const float ang = labels[b] * freqs[k];
+  out[(size_t)b * 2 * nf + k] = cosf(ang);
+  out[(size_t)b * 2 * nf + nf + k] = sinf(ang);
+}
+
+int launch_pos_embed(const float* labels, int Bc, const float* freqs, int nf, float* out, hipStream_t s) {
+  hipLaunchKernelGGL(k_pos_embed, dim3(cdiv(Bc * nf, 256)), dim3(256), 0, s, labels, Bc, freqs, nf, out);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// EDM preconditioning coefficients (runner/objectives/edm.py:122-126), sigma_data = 0.5.
+__global__ void k_edm_coef(const float* __restrict__ labels, int B, int uniform, int mode, float* __restrict__ coef,
+                           float* __restrict__ c_noise) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float s = labels[uniform ? 0 : b];
+  float c_skip = 0.f, c_out = 1.f, c_in = 1.f, c_n = s;
+  if (mode == 1) {
+    const float d = s * s + 0.25f;
+    c_skip = 0.25f / d;
+    c_out = s * 0.5f / sqrtf(d);
+    c_in = 1.0f / sqrtf(d);
+    c_n = logf(s) * 0.25f;
+  }
+  coef[4 * b + 0] = c_skip;
+  coef[4 * b + 1] = c_out;
+  coef[4 * b + 2] = c_in;
+  coef[4 * b + 3] = c_n;
+  if (!uniform || b == 0) c_noise[b] = c_n;
+}
+
+int launch_edm_coef(const float* labels, int B, int uniform, int mode, float* coef, float* c_noise, hipStream_t s) {
+  hipLaunchKernelGGL(k_edm_coef, dim3(cdiv(B, 64)), dim3(64), 0, s, labels, B, uniform, mode, coef, c_noise);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// PatchEmbed (swin_gnn.py:562-577) with the self-conditioning concat (:769-771) and the c_in scaling
+// of Precond (precond.py:47) folded into the gather: conv(k=s=p) -> LN -> silu(shift + y(1+scale)).
+// ------------------------------------------------------------------------------------------------
+struct EmbedArgs {
+  const float* x; const float* sc; const float* c_in; int c_in_stride;
+  const float* cond; int cond_stride, cond_off;
+  const float* w; const float* bias; const float* g; const float* b;
+  float* tok;
+  int B, N, p, in_ch, C, self_cond;
+};
+
+template <int LANES, int V>
+__global__ __launch_bounds__(256) void k_patch_embed(EmbedArgs a) {
+  constexpr int RPB = 256 / LANES;
+  const int hp = a.N / a.p;
+  const int L = hp * hp;
+  const int row = blockIdx.x * RPB + (int)threadIdx.x / LANES;
+  const int g = threadIdx.x % LANES;
+  if (row >= a.B * L) return;
+  const int bi = row / L;
+  const int rem = row - bi * L;
+  const int Y = rem / hp, X = rem - Y * hp;
+  const int pp = a.p * a.p;
+  const int kin = a.in_ch * pp;
+  const int nch = a.C >> 2;
+  const float cin = a.c_in ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f;
+
+  float in[32];
+#pragma unroll
+  for (int k = 0; k < 32; ++k) {
+    in[k] = 0.f;
+    if (k < kin) {
+      const int ci = k / pp, ij = k - ci * pp;
+      const int i = ij / a.p, j = ij - i * a.p;
+      const size_t off = ((size_t)bi * a.N + (Y * a.p + i)) * a.N + (X * a.p + j);
+      const bool is_x = (!a.self_cond) || ci == a.in_ch - 1;  // cat([self_cond, x]) : last channel is x
+      if (is_x) in[k] = cin * a.x[off];
+      else if (a.sc) in[k] = a.sc[off];
+    }
+  }
+  float4 v[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = g + i * LANES;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nch) {
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* wr = a.w + (size_t)(4 * c + e) * kin;
+        float acc = a.bias[4 * c + e];
+#pragma unroll
+        for (int k = 0; k < 32; ++k)
+          if (k < kin) acc += in[k] * wr[k];
+        o[e] = acc;
+      }
+      v[i] = make_float4(o[0], o[1], o[2], o[3]);
+    }
+  }
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  const float mean = group_sum<LANES>(s) / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+    if (g + i * LANES < nch) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float rstd = 1.0f / sqrtf(group_sum<LANES>(q) / (float)a.C + 1e-5f);
+  const float* crow = a.cond + (size_t)bi * a.cond_stride + a.cond_off;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = g + i * LANES;
+    if (c < nch) {
+      const float4 gg = *reinterpret_cast<const float4*>(a.g + 4 * c);
+      const float4 bb = *reinterpret_cast<const float4*>(a.b + 4 * c);
+      const float4 sc = *reinterpret_cast<const float4*>(crow + 4 * c);
+      const float4 sh = *reinterpret_cast<const float4*>(crow + a.C + 4 * c);
+      float4 y;
+      y.x = silu_f(sh.x + ((v[i].x - mean) * rstd * gg.x + bb.x) * (sc.x + 1.f));
+      y.y = silu_f(sh.y + ((v[i].y - mean) * rstd * gg.y + bb.y) * (sc.y + 1.f));
+      y.z = silu_f(sh.z + ((v[i].z - mean) * rstd * gg.z + bb.z) * (sc.z + 1.f));
+      y.w = silu_f(sh.w + ((v[i].w - mean) * rstd * gg.w + bb.w) * (sc.w + 1.f));
+      *reinterpret_cast<float4*>(a.tok + (size_t)row * a.C + 4 * c) = y;
+    }
+  }
+}
+
+int launch_patch_embed(const swg_net* net, int B, const float* x, const float* sc, const float* c_in, int c_in_stride,
+                       const float* cond, int cond_stride, float* tok, hipStream_t s) {
+  const int kin = net->in_ch * net->p * net->p;
+  if (kin > 32 || net->N % net->p || net->C0 % 4) return SWG_E_UNSUPPORTED;
+  if (net->self_cond ? net->in_ch != 2 : net->in_ch != 1) return SWG_E_UNSUPPORTED;
+  EmbedArgs a = {x, sc, c_in, c_in_stride, cond, cond_stride, net->pe_cond_off, net->pe_w, net->pe_b,
+                 net->pe_ln.g, net->pe_ln.b, tok, B, net->N, net->p, net->in_ch, net->C0, net->self_cond};
+  const int hp = net->N / net->p;
+  const int rows = B * hp * hp;
+  RowGeom geo = row_geom(net->C0 / 4);
+#define CALL(LN, VV) hipLaunchKernelGGL((k_patch_embed<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256), 0, s, a)
+  SWG_ROW_DISPATCH(geo, CALL);
+#undef CALL
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// Final LayerNorm (swin_gnn.py:748) + collapsed read-out (:697-701): per token C -> p*p values.
+// ------------------------------------------------------------------------------------------------
+struct ReadoutArgs {
+  const float* tok; const float* g; const float* b; const float* w; float bias; float* F;
+  int B, N, p, C;
+};
+
+template <int LANES, int V>
+__global__ __launch_bounds__(256) void k_final_readout(ReadoutArgs a) {
+  constexpr int RPB = 256 / LANES;
+  const int hp = a.N / a.p;
+  const int L = hp * hp;
+  const int row = blockIdx.x * RPB + (int)threadIdx.x / LANES;
+  const int g = threadIdx.x % LANES;
+  if (row >= a.B * L) return;
+  const int nch = a.C >> 2;
+  float4 v[V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = g + i * LANES;
+    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < nch) v[i] = *reinterpret_cast<const float4*>(a.tok + (size_t)row * a.C + 4 * c);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = group_sum<LANES>(s) / (float)a.C;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+    if (g + i * LANES < nch) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float rstd = 1.0f / sqrtf(group_sum<LANES>(q) / (float)a.C + 1e-5f);
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = g + i * LANES;
+    if (c < nch) {
+      const float4 gg = *reinterpret_cast<const float4*>(a.g + 4 * c);
+      const float4 bb = *reinterpret_cast<const float4*>(a.b + 4 * c);
+      v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
+      v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
+      v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
+      v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
+    }
+  }
+  const int pp = a.p * a.p;
+  const int bi = row / L;
+  const int rem = row - bi * L;
+  const int Y = rem / hp, X = rem - Y * hp;
+#pragma unroll
+  for (int o = 0; o < 16; ++o) {
+    if (o < pp) {
+      float acc = 0.f;
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int c = g + i * LANES;
+        if (c < nch) {
+          const float* wr = a.w + (size_t)(4 * c) * pp + o;
+          acc += (v[i].x * wr[0] + v[i].y * wr[pp]) + (v[i].z * wr[2 * pp] + v[i].w * wr[3 * pp]);
+        }
+      }
+      acc = group_sum<LANES>(acc) + a.bias;
+      if (g == (o % LANES)) {
+        const int i2 = o / a.p, j2 = o - i2 * a.p;
+        a.F[((size_t)bi * a.N + (Y * a.p + i2)) * a.N + (X * a.p + j2)] = acc;
+      }
+    }
+  }
+}
+
+int launch_final_readout(const swg_net* net, int B, const float* tok, float* F, hipStream_t s) {
+  if (net->p * net->p > 16) return SWG_E_UNSUPPORTED;
+  ReadoutArgs a = {tok, net->norm.g, net->norm.b, net->ro_w, net->ro_b, F, B, net->N, net->p, net->C0};
+  const int hp = net->N / net->p;
+  const int rows = B * hp * hp;
+  RowGeom geo = row_geom(net->C0 / 4);
+#define CALL(LN, VV) hipLaunchKernelGGL((k_final_readout<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256), 0, s, a)
+  SWG_ROW_DISPATCH(geo, CALL);
+#undef CALL
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
+// N x N adjacency kernels, tiled 32 x 32 through LDS so both A[r][c] and A[c][r] are read coalesced.
+// ------------------------------------------------------------------------------------------------
+__device__ __forceinline__ float block_sum_256(float v, float* red) {
+  v = group_sum<64>(v);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = v;
+  __syncthreads();
+  return red[0] + red[1] + red[2] + red[3];
+}
+
+// out = mask(c_skip*x + c_out*0.5*(Fm + Fm^T)), Fm = mask(F): swin_gnn.py:777-778, precond.py:49-51
+__global__ __launch_bounds__(256) void k_sym_precond(int N, const float* __restrict__ F, const float* __restrict__ x,
+                                                     const float* __restrict__ flags, const float* __restrict__ coef,
+                                                     float* __restrict__ out, float* __restrict__ sym_err) {
+  __shared__ float tF[32][33];
+  __shared__ float tX[32][33];
+  __shared__ float red[4];
+  const int bi = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t base = (size_t)bi * N * N;
+  const float c_skip = coef ? coef[4 * bi + 0] : 0.f;
+  const float c_out = coef ? coef[4 * bi + 1] : 1.f;
+  // transposed tile: rows c0.., cols r0..
+  for (int k = ty; k < 32; k += 8) {
+    const int rr = c0 + k, cc = r0 + tx;
+    const bool ok = rr < N && cc < N;
+    tF[k][tx] = ok ? F[base + (size_t)rr * N + cc] : 0.f;
+    tX[k][tx] = (ok && sym_err && x) ? x[base + (size_t)rr * N + cc] : 0.f;
+  }
+  __syncthreads();
+  float err = 0.f;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < N && c < N) {
+      const bool m = flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f;
+      float v = 0.f;
+      if (m) {
+        const float sym = 0.5f * (F[base + (size_t)r * N + c] + tF[tx][k]);
+        const float xv = x ? x[base + (size_t)r * N + c] : 0.f;
+        v = c_skip * xv + c_out * sym;
+        if (sym_err) err += fabsf(v - (c_skip * tX[tx][k] + c_out * sym));
+      }
+      out[base + (size_t)r * N + c] = v;
+    }
+  }
+  if (sym_err) {
+    err = block_sum_256(err, red);
+    if (threadIdx.x == 0 && err != 0.f) atomicAdd(sym_err, err);
+  }
+}
+
+int launch_sym_precond(int B, int N, const float* F, const float* x, const float* flags, const float* coef, float* out,
+                       float* sym_err, hipStream_t s) {
+  dim3 grid(cdiv(N, 32), cdiv(N, 32), B);
+  hipLaunchKernelGGL(k_sym_precond, grid, dim3(256), 0, s, N, F, x, flags, coef, out, sym_err);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// x_hat = mask(x + coef * sym(raw)); sym(raw)[r][c] = raw[min][max] off the diagonal, 0 on it.
+__global__ __launch_bounds__(256) void k_heun_churn(int N, const float* __restrict__ x, const float* __restrict__ raw,
+                                                    const float* __restrict__ flags, float coef,
+                                                    float* __restrict__ xh) {
+  __shared__ float tR[32][33];
+  const int bi = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t base = (size_t)bi * N * N;
+  for (int k = ty; k < 32; k += 8) {
+    const int rr = c0 + k, cc = r0 + tx;
+    tR[k][tx] = (rr < N && cc < N) ? raw[base + (size_t)rr * N + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < N && c < N) {
+      const bool m = flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f;
+      float v = 0.f;
+      if (m) {
+        const float e = (r < c) ? raw[base + (size_t)r * N + c] : ((r > c) ? tR[tx][k] : 0.f);
+        v = x[base + (size_t)r * N + c] + coef * e;
+      }
+      xh[base + (size_t)r * N + c] = v;
+    }
+  }
+}
+
+// d = mask((1/t) x_hat - (1/t) mask(D)); x' = x_hat + h d   (mcmc_sampler/edm.py:188-193, 197)
+__global__ __launch_bounds__(256) void k_heun_euler(int N, size_t total, const float* __restrict__ xh,
+                                                    const float* __restrict__ den, const float* __restrict__ flags,
+                                                    float inv_t, float h, int mask_out, float* __restrict__ d_cur,
+                                                    float* __restrict__ xp) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t nn = (size_t)N * N;
+  const int bi = (int)(i / nn);
+  const int rem = (int)(i - (size_t)bi * nn);
+  const int r = rem / N, c = rem - r * N;
+  const bool m = flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f;
+  const float xv = xh[i];
+  const float d = m ? (inv_t * xv - inv_t * den[i]) : 0.f;
+  if (d_cur) d_cur[i] = d;
+  const float o = xv + h * d;
+  xp[i] = (mask_out && !m) ? 0.f : o;
+}
+
+// d' = (1/t') x' - (1/t') D2 ; x+ = mask(x_hat + h (0.5 d + 0.5 d'))   (mcmc_sampler/edm.py:211-215)
+__global__ __launch_bounds__(256) void k_heun_correct(int N, size_t total, const float* __restrict__ xh,
+                                                      const float* __restrict__ xp, const float* __restrict__ d_cur,
+                                                      const float* __restrict__ den2, const float* __restrict__ flags,
+                                                      float inv_tp, float h, float* __restrict__ xn) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t nn = (size_t)N * N;
+  const int bi = (int)(i / nn);
+  const int rem = (int)(i - (size_t)bi * nn);
+  const int r = rem / N, c = rem - r * N;
+  const bool m = flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f;
+  float o = 0.f;
+  if (m) {
+    const float dp = inv_tp * xp[i] - inv_tp * den2[i];
+    o = xh[i] + h * (0.5f * d_cur[i] + 0.5f * dp);
+  }
+  xn[i] = o;
+}
+
+__global__ __launch_bounds__(256) void k_mask_adjs(int N, size_t total, float* __restrict__ a,
+                                                   const float* __restrict__ flags) {
+  const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const size_t nn = (size_t)N * N;
+  const int bi = (int)(i / nn);
+  const int rem = (int)(i - (size_t)bi * nn);
+  const int r = rem / N, c = rem - r * N;
+  if (flags[(size_t)bi * N + r] == 0.f || flags[(size_t)bi * N + c] == 0.f) a[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256) void k_sym_check(int N, const float* __restrict__ a, float* __restrict__ acc) {
+  __shared__ float tA[32][33];
+  __shared__ float red[4];
+  const int bi = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t base = (size_t)bi * N * N;
+  for (int k = ty; k < 32; k += 8) {
+    const int rr = c0 + k, cc = r0 + tx;
+    tA[k][tx] = (rr < N && cc < N) ? a[base + (size_t)rr * N + cc] : 0.f;
+  }
+  __syncthreads();
+  float err = 0.f;
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < N && c < N) err += fabsf(a[base + (size_t)r * N + c] - tA[tx][k]);
+  }
+  err = block_sum_256(err, red);
+  if (threadIdx.x == 0 && err != 0.f) atomicAdd(acc, err);
+}
+
+extern "C" {
+
+int swg_heun_churn(int32_t B, int32_t N, const float* x, const float* raw_noise, const float* node_flags,
+                   float noise_coef, float* x_hat, void* stream) {
+  if (!x || !raw_noise || !node_flags || !x_hat) return SWG_E_NULL;
+  if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  hipLaunchKernelGGL(k_heun_churn, dim3(cdiv(N, 32), cdiv(N, 32), B), dim3(256), 0, (hipStream_t)stream, N, x,
+                     raw_noise, node_flags, noise_coef, x_hat);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_heun_euler(int32_t B, int32_t N, const float* x_hat, const float* denoised, const float* node_flags,
+                   float t_hat, float h, int32_t mask_out, float* d_cur, float* x_prime, void* stream) {
+  if (!x_hat || !denoised || !node_flags || !x_prime) return SWG_E_NULL;
+  if (B <= 0 || N <= 0 || t_hat == 0.f) return SWG_E_SHAPE;
+  const size_t total = (size_t)B * N * N;
+  hipLaunchKernelGGL(k_heun_euler, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, total,
+                     x_hat, denoised, node_flags, 1.0f / t_hat, h, mask_out, d_cur, x_prime);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_prime, const float* d_cur,
+                     const float* denoised2, const float* node_flags, float t_prime, float h, float* x_next,
+                     void* stream) {
+  if (!x_hat || !x_prime || !d_cur || !denoised2 || !node_flags || !x_next) return SWG_E_NULL;
+  if (B <= 0 || N <= 0 || t_prime == 0.f) return SWG_E_SHAPE;
+  const size_t total = (size_t)B * N * N;
+  hipLaunchKernelGGL(k_heun_correct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
+                     total, x_hat, x_prime, d_cur, denoised2, node_flags, 1.0f / t_prime, h, x_next);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_mask_adjs(int32_t B, int32_t N, float* a, const float* node_flags, void* stream) {
+  if (!a || !node_flags) return SWG_E_NULL;
+  if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  const size_t total = (size_t)B * N * N;
+  hipLaunchKernelGGL(k_mask_adjs, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, total,
+                     a, node_flags);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_sym_check(int32_t B, int32_t N, const float* a, float* acc, void* stream) {
+  if (!a || !acc) return SWG_E_NULL;
+  if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  hipLaunchKernelGGL(k_sym_check, dim3(cdiv(N, 32), cdiv(N, 32), B), dim3(256), 0, (hipStream_t)stream, N, a, acc);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+}  // extern "C"

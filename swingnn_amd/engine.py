@@ -1,0 +1,210 @@
+"""Host-side plumbing between the nn.Module parameter tree and libswingnn_hip.so.
+
+A ``NetCache`` holds everything the kernels consume that is DERIVED from the fp32 nn.Parameters:
+bf16 / K-padded copies of the Linear weights, the stacked affine layers, the collapsed read-out and
+the C descriptor structs (include/swingnn_hip.h).  It is rebuilt whenever a parameter's version
+counter, storage or device changes.  PyTorch is used only for device memory and streams.
+"""
+import ctypes as C
+
+import torch
+
+from . import _lib as L
+
+
+def eff_window(res: int, window: int, shift: int):
+    """Window clamp rule of the reference block constructor (model/swin_gnn/swin_gnn.py:189-192)."""
+    if res <= window:
+        return res, 0
+    return window, shift
+
+
+def _kp(k: int) -> int:
+    return (k + 31) // 32 * 32
+
+
+def _ptr(t):
+    return None if t is None else t.data_ptr()
+
+
+def stream_ptr():
+    return torch.cuda.current_stream().cuda_stream
+
+
+_WS = {}
+
+
+def workspace(device, nbytes: int) -> torch.Tensor:
+    """Scratch buffer from torch's caching allocator, reused across calls on one device."""
+    key = (device.index if device.index is not None else torch.cuda.current_device())
+    buf = _WS.get(key)
+    if buf is None or buf.numel() < nbytes:
+        buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
+        _WS[key] = buf
+    return buf
+
+
+def _f32(t: torch.Tensor) -> torch.Tensor:
+    t = t.detach()
+    if t.dtype != torch.float32 or not t.is_contiguous():
+        t = t.to(torch.float32).contiguous()
+    return t
+
+
+class Keep:
+    """Collects the tensors / ctypes objects a descriptor points into."""
+
+    def __init__(self):
+        self.items = []
+
+    def __call__(self, obj):
+        self.items.append(obj)
+        return obj
+
+    def f32(self, t):
+        return _ptr(self(_f32(t)))
+
+    def lin(self, weight, bias=None) -> L.SwgLin:
+        w = weight.detach()
+        N, K = w.shape
+        Kp = _kp(K)
+        wb = torch.zeros((N, Kp), dtype=torch.bfloat16, device=w.device)
+        wb[:, :K] = w
+        self(wb)
+        return L.SwgLin(_ptr(wb), None if bias is None else self.f32(bias), N, K, Kp)
+
+    def ln(self, mod) -> L.SwgLn:
+        return L.SwgLn(self.f32(mod.weight), self.f32(mod.bias))
+
+
+def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
+    return L.SwgBlock(blk.dim, blk.input_resolution[0], blk.window_size, blk.shift_size, blk.num_heads, cond_off,
+                      keep.ln(blk.norm1), keep.ln(blk.norm2),
+                      keep.lin(blk.attn.qkv.weight, blk.attn.qkv.bias), keep.lin(blk.attn.proj.weight, blk.attn.proj.bias),
+                      keep.lin(blk.mlp.fc1.weight, blk.mlp.fc1.bias), keep.lin(blk.mlp.fc2.weight, blk.mlp.fc2.bias),
+                      keep.f32(blk.attn.relative_position_bias_table))
+
+
+def merge_desc(keep: Keep, m) -> L.SwgMerge:
+    return L.SwgMerge(m.dim, m.input_resolution[0], keep.ln(m.norm), keep.lin(m.reduction.weight))
+
+
+def breakup_desc(keep: Keep, u) -> L.SwgBreakup:
+    return L.SwgBreakup(u.dim, u.input_resolution[0], keep.lin(u.pre_linear.weight), keep.ln(u.norm),
+                        keep.ln(u.post_norm), keep.lin(u.post_linear.weight))
+
+
+def collapse_read_out(read_out, p: int):
+    """ConvTranspose2d(C,C,p,p) -> Conv1x1(C,C) -> Conv1x1(C,1) has no non-linearity in between
+    (model/swin_gnn/swin_gnn.py:697-701): one [C] -> [p*p] affine map per token.  float64 on device."""
+    W0 = read_out[0].weight.detach().double()              # [Cin, Cout, p, p]
+    W1 = read_out[1].weight.detach().double()[:, :, 0, 0]  # [C1, C0]
+    W2 = read_out[2].weight.detach().double()[0, :, 0, 0]  # [C1]
+    v = W2 @ W1
+    weff = torch.einsum("o,ioyx->iyx", v, W0).reshape(W0.shape[0], p * p)
+    beff = v @ read_out[0].bias.detach().double() + W2 @ read_out[1].bias.detach().double() \
+        + read_out[2].bias.detach().double()[0]
+    return weff.float().contiguous(), float(beff)
+
+
+class NetCache:
+    """Descriptor + derived weights of one SwinGNN module on one device."""
+
+    def __init__(self, model):
+        keep = self.keep = Keep()
+        dev = model.norm.weight.device
+        if dev.type != "cuda":
+            raise RuntimeError("swingnn_amd runs on an MI355X only (module parameters are on %s); there is no "
+                               "CPU fallback" % dev)
+        self.device = dev
+        C0 = model.embed_dim
+        # conditioning vector layout: patch_embed first, then every block in execution order
+        aff_w, aff_b = [model.patch_embed.affine.weight], [model.patch_embed.affine.bias]
+        off = 2 * C0
+        self.layer_objs = []
+        layers = (L.SwgLayer * (2 * model.num_layers))()
+        for li, layer in enumerate(list(model.down_layers) + list(model.up_layers)):
+            blocks = (L.SwgBlock * len(layer.blocks))()
+            for j, blk in enumerate(layer.blocks):
+                blocks[j] = block_desc(keep, blk, off)
+                aff_w.append(blk.affine.weight)
+                aff_b.append(blk.affine.bias)
+                off += 2 * blk.dim
+            down = C.pointer(keep(merge_desc(keep, layer.downsample))) if layer.downsample is not None else None
+            up = C.pointer(keep(breakup_desc(keep, layer.upsample))) if layer.upsample is not None else None
+            keep(blocks)
+            layers[li] = L.SwgLayer(len(layer.blocks), int(li >= model.num_layers),
+                                    C.cast(blocks, C.POINTER(L.SwgBlock)),
+                                    down if down is not None else C.POINTER(L.SwgMerge)(),
+                                    up if up is not None else C.POINTER(L.SwgBreakup)())
+        keep(layers)
+        self.cond_total = off
+        aw = keep(torch.cat([_f32(w) for w in aff_w], dim=0).contiguous())
+        ab = keep(torch.cat([_f32(b) for b in aff_b], dim=0).contiguous())
+        half = C0 // 2
+        freqs = torch.arange(0, half, dtype=torch.float32, device=dev) / half
+        freqs = keep(((1 / 10000) ** freqs).contiguous())  # PositionalEmbedding, swin_gnn.py:508-510
+        p = model.patch_embed.patch_size[0]
+        ro_w, ro_b = collapse_read_out(model.read_out, p)
+        keep(ro_w)
+        pe = model.patch_embed
+        pe_w = keep(_f32(pe.proj.weight).reshape(C0, -1).contiguous())
+        self.net = L.SwgNet(
+            pe.img_size[0], p, pe.in_chans, C0, 2 * model.num_layers, int(model.self_condition), off, 0,
+            _ptr(freqs), keep.f32(model.map_layer0.weight), keep.f32(model.map_layer0.bias),
+            keep.f32(model.map_layer1.weight), keep.f32(model.map_layer1.bias),
+            _ptr(aw), _ptr(ab), _ptr(pe_w), keep.f32(pe.proj.bias), keep.ln(pe.norm),
+            C.cast(layers, C.POINTER(L.SwgLayer)), keep.ln(model.norm), _ptr(ro_w), ro_b)
+        self.layers = layers
+        self._ws_bytes = {}
+
+    def ws_bytes(self, B: int) -> int:
+        n = self._ws_bytes.get(B)
+        if n is None:
+            n = int(L.lib.swg_workspace_bytes(C.byref(self.net), B))
+            if n == 0:
+                raise L.SwgError("swg_workspace_bytes: unsupported network geometry")
+            self._ws_bytes[B] = n
+        return n
+
+    def block(self, li: int, j: int) -> L.SwgBlock:
+        return self.layers[li].blocks[j]
+
+
+def params_key(model):
+    ps = list(model.parameters())
+    return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), str(ps[0].device))
+
+
+def get_cache(model) -> NetCache:
+    key = params_key(model)
+    if getattr(model, "_swg_key", None) != key:
+        model._swg_cache = NetCache(model)
+        model._swg_key = key
+    return model._swg_cache
+
+
+def _as_f32(t: torch.Tensor) -> torch.Tensor:
+    if t.dtype != torch.float32:
+        t = t.to(torch.float32)
+    return t if t.is_contiguous() else t.contiguous()
+
+
+def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_uniform: bool, self_cond, out=None,
+                 sym_err=None):
+    """One pass of the network through swg_precond_forward (mode 0: SwinGNN.forward, mode 1: Precond core)."""
+    x = _as_f32(x)
+    flags = _as_f32(node_flags)
+    labels = _as_f32(labels)
+    sc = None if self_cond is None else _as_f32(self_cond)
+    B, N = x.shape[0], x.shape[-1]
+    if x.dim() != 3 or x.shape[1] != N or N != cache.net.N:
+        raise AssertionError(f"Input image size ({x.shape[-2]}*{N}) doesn't match model ({cache.net.N}*{cache.net.N}).")
+    if out is None:
+        out = torch.empty_like(x)
+    nbytes = cache.ws_bytes(B)
+    ws = workspace(x.device, nbytes)
+    L.check(L.lib.swg_precond_forward(C.byref(cache.net), B, mode, x.data_ptr(), flags.data_ptr(), labels.data_ptr(),
+                                      int(labels_uniform), _ptr(sc), out.data_ptr(), _ptr(sym_err), ws.data_ptr(),
+                                      ws.numel(), stream_ptr()), "swg_precond_forward")
+    return out

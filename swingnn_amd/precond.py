@@ -1,0 +1,66 @@
+"""Drop-in EDM preconditioner (reference model/precond/precond.py:9-57) on the HIP network pass.
+
+``Precond(precond, model, self_condition)`` and ``forward(x, node_flags, sigmas, self_cond=None)`` keep
+the reference signature.  The c_in scaling, the ln(sigma)/4 noise label, the c_skip/c_out epilogue, the
+masks and the (F+F^T)/2 symmetrisation all run inside swg_precond_forward.  Reference quirks that are
+kept on purpose: the passed ``self_cond`` is discarded (:39) and the numpy coin is flipped in eval mode
+too (:40).  The per-call symmetry assert (:52, a host sync) is replaced by a device-side accumulator
+that ``assert_symmetric()`` reads on demand (``symmetry_check='eager'`` restores the per-call assert).
+"""
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import engine as E
+from .swin_gnn import SwinGNN
+
+
+class Precond(nn.Module):
+    def __init__(self, precond, model, self_condition):
+        super().__init__()
+        assert precond in ['vp', 've', 'edm']
+        if precond != 'edm':
+            raise NotImplementedError("swingnn_amd.Precond implements precond='edm' (every shipped SwinGNN config)")
+        if not isinstance(model, SwinGNN):
+            raise TypeError("swingnn_amd.Precond wraps swingnn_amd.SwinGNN")
+        self.precond = precond
+        self.model = model
+        self.self_condition = self_condition
+        self.symmetry_check = 'deferred'
+        self._sym_acc = None
+
+    def _acc(self, device):
+        if self._sym_acc is None or self._sym_acc.device != device:
+            self._sym_acc = torch.zeros(1, dtype=torch.float32, device=device)
+        return self._sym_acc
+
+    def forward(self, x, node_flags, sigmas, self_cond=None, *args, **model_kwargs):
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
+            raise NotImplementedError("swingnn_amd: backward kernels are not built yet; run under torch.no_grad()")
+        sigmas = torch.as_tensor(sigmas, device=x.device).reshape(-1)
+        uniform = sigmas.numel() == 1 or (sigmas.dim() == 1 and sigmas.stride(0) == 0)  # sampler: .expand(B), edm.py:180
+        if not uniform and sigmas.numel() != x.shape[0]:
+            raise AssertionError("sigmas must have one entry per sample")
+        labels = sigmas[:1] if uniform else sigmas
+        cache = E.get_cache(self.model)
+        sc = None  # the argument is discarded, precond.py:39
+        if self.self_condition and np.random.rand() < 0.5:
+            sc = E.network_pass(cache, 1, x, node_flags, labels, uniform, None)
+        acc = None if self.symmetry_check == 'off' else self._acc(x.device)
+        D = E.network_pass(cache, 1, x, node_flags, labels, uniform, sc if self.model.self_condition else None,
+                           sym_err=acc)
+        if self.symmetry_check == 'eager':
+            self.assert_symmetric()
+        return D
+
+    def assert_symmetric(self):
+        """Host-visible form of check_adjs_symmetry (utils/graph_utils.py:89-94) over every forward since the
+        last call."""
+        if self._sym_acc is not None:
+            err = float(self._sym_acc.item())
+            self._sym_acc.zero_()
+            assert err < 1e-2, f"denoised adjacency is not symmetric: sum|D-D^T| = {err}"
+
+    @staticmethod
+    def round_sigma(sigma):
+        return torch.as_tensor(sigma)

@@ -1,0 +1,271 @@
+"""GPU parity: the HIP path (through the C-ABI library) against the CPU oracle and against the golden
+vectors produced by the reference modules.
+
+Tolerances (bf16 MFMA operands, fp32 accumulate / softmax / LayerNorm / residual stream):
+  * 'init' regime (weights of the reference's own initialisation scale): the north-star bar --
+    max-abs error on the denoised adjacency <= 1e-2, thresholded adjacency identical on >= 99.9 % of the
+    entries that are further than the tolerance from the decision boundary.
+  * 'stress' regime (unit-gain weights, O(1..10) activations): error relative to the output scale,
+    max <= 4e-2 * scale and mean <= 5e-3 * scale (bf16 has 8 significant bits).
+  * fp32-only kernels (Heun updates, masks): 1e-6 relative.
+"""
+import numpy as np
+import pytest
+import torch
+
+from oracle import filler
+from oracle import swingnn_ref as O
+from tests import helpers as H
+from tests.golden.cases import BLOCK_CASES, EMBED_CASES, MERGE_CASES, NET_CASES, SAMPLER_CASES
+
+pytestmark = pytest.mark.gpu
+torch.set_grad_enabled(False)
+
+
+@pytest.fixture(scope="module")
+def S():
+    assert torch.cuda.is_available(), "GPU tests need an MI355X"
+    import swingnn_amd
+    return swingnn_amd
+
+
+DEV = "cuda:0"
+
+
+def rel_close(out, ref, max_rel=4e-2, mean_rel=5e-3):
+    out = out.detach().float().cpu()
+    ref = torch.as_tensor(ref).float()
+    assert out.shape == ref.shape, (out.shape, ref.shape)
+    assert torch.isfinite(out).all()
+    scale = max(float(ref.abs().max()), 1e-3)
+    err = (out - ref).abs()
+    assert float(err.max()) <= max_rel * scale, f"max err {float(err.max()):.4g} vs scale {scale:.4g}"
+    assert float(err.mean()) <= mean_rel * scale, f"mean err {float(err.mean()):.4g} vs scale {scale:.4g}"
+
+
+def strip(sd, prefix):
+    return {k[len(prefix):]: v for k, v in sd.items() if k.startswith(prefix)}
+
+
+def load(module, sd):
+    own = module.state_dict()
+    use = {k: v for k, v in sd.items() if k in own and torch.is_floating_point(v) and not k.endswith("attn_mask")}
+    missing = [k for k in own if k not in use and torch.is_floating_point(own[k]) and not k.endswith("attn_mask")]
+    assert not missing, missing
+    module.load_state_dict(use, strict=False)
+    return module.to(DEV).eval()
+
+
+# ---------------------------------------------------------------------------------------------
+@pytest.mark.parametrize("name", list(BLOCK_CASES))
+def test_swin_block(S, golden, name):
+    c = BLOCK_CASES[name]
+    w, s = O.eff_window(c["res"], c["window"], c["shift"])
+    sd = strip(H.block_state(c["C"], c["heads"], w, c["seed"]), "blk.")
+    blk = load(S.SwinTransformerBlock(c["C"], 512, (c["res"],) * 2, c["heads"], c["window"], c["shift"]), sd)
+    assert (blk.window_size, blk.shift_size) == (w, s)
+    x = filler.uniform("x", (c["B"], c["res"] ** 2, c["C"]), c["seed"])
+    emb = filler.uniform("emb", (c["B"], 512), c["seed"])
+    out = blk(x.to(DEV), emb.to(DEV))
+    rel_close(out, golden[f"block/{name}/out"])
+    # and against the oracle run here (same numbers as the golden within fp32 noise)
+    ref = O.swin_block(x, emb, H.block_state(c["C"], c["heads"], w, c["seed"]), "blk", c["res"], c["heads"],
+                       c["window"], c["shift"])
+    rel_close(out, ref)
+
+
+def test_block_attention_half_only(S):
+    """swg_wattn_fwd alone (no MLP) against the oracle's attention half, shifted 6x6 windows."""
+    import ctypes as C
+    from swingnn_amd import _lib as L, engine as E
+    c = BLOCK_CASES["r12_w6_s3"]
+    full = H.block_state(c["C"], c["heads"], 6, c["seed"])
+    blk = load(S.SwinTransformerBlock(c["C"], 512, (12, 12), c["heads"], 6, 3), strip(full, "blk."))
+    x = filler.uniform("x", (c["B"], 144, c["C"]), 5)
+    emb = filler.uniform("emb", (c["B"], 512), 5)
+    # oracle: zero the MLP so that swin_block returns the attention half
+    z = dict(full)
+    z["blk.mlp.fc2.weight"] = torch.zeros_like(z["blk.mlp.fc2.weight"])
+    z["blk.mlp.fc2.bias"] = torch.zeros_like(z["blk.mlp.fc2.bias"])
+    ref = O.swin_block(x, emb, z, "blk", 12, c["heads"], 6, 3)
+    keep = E.Keep()
+    desc = E.block_desc(keep, blk, 0)
+    cond = (emb @ full["blk.affine.weight"].t() + full["blk.affine.bias"]).to(DEV).contiguous()
+    xd = x.to(DEV)
+    out = torch.empty_like(xd)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    L.check(L.lib.swg_wattn_fwd(C.byref(desc), c["B"], xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out.data_ptr(),
+                                ws.data_ptr(), ws.numel(), E.stream_ptr()), "swg_wattn_fwd")
+    rel_close(out, ref)
+    # workspace too small / bad batch are reported, not executed
+    assert L.lib.swg_wattn_fwd(C.byref(desc), c["B"], xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out.data_ptr(),
+                               ws.data_ptr(), 1024, E.stream_ptr()) == -3
+    assert L.lib.swg_wattn_fwd(C.byref(desc), 0, xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out.data_ptr(),
+                               ws.data_ptr(), ws.numel(), E.stream_ptr()) == -1
+
+
+@pytest.mark.parametrize("name", list(MERGE_CASES))
+def test_merge_breakup(S, golden, name):
+    c = MERGE_CASES[name]
+    m = load(S.PatchMerging((c["res"],) * 2, c["C"]), strip(H.merge_state(c["C"], c["seed"]), "m."))
+    x = filler.uniform("x", (c["B"], c["res"] ** 2, c["C"]), c["seed"])
+    rel_close(m(x.to(DEV)), golden[f"merge/{name}"])
+    u = load(S.PatchBreakup((c["res"] // 2,) * 2, 4 * c["C"]), strip(H.breakup_state(4 * c["C"], c["seed"]), "u."))
+    xb = filler.uniform("xb", (c["B"], (c["res"] // 2) ** 2, 4 * c["C"]), c["seed"])
+    rel_close(u(xb.to(DEV)), golden[f"breakup/{name}"])
+
+
+@pytest.mark.parametrize("name", ["p4_in2", "p3_in2"])
+def test_patch_embed(S, golden, name):
+    c = EMBED_CASES[name]
+    pe = load(S.PatchEmbed(c["N"], c["p"], c["in"], c["C"], 512, torch.nn.LayerNorm),
+              strip(H.embed_state(c["C"], c["in"], c["p"], c["seed"]), "pe."))
+    x = filler.uniform("x", (c["B"], c["in"], c["N"], c["N"]), c["seed"])
+    emb = filler.uniform("emb", (c["B"], 512), c["seed"])
+    out = pe(x.to(DEV), emb.to(DEV), None)
+    rel_close(out, golden[f"embed/{name}"], 1e-4, 1e-5)  # fp32 kernel
+
+
+# ---------------------------------------------------------------------------------------------
+def build_precond(S, name, golden_meta, regime, seed=None):
+    c = NET_CASES[name]
+    cfg = c["cfg"]
+    net = S.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=cfg["in_chans"],
+                    embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                    window_size=cfg["window_size"], mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                    drop_path_rate=0.0, self_condition=cfg["self_condition"])
+    pre = S.Precond("edm", net, cfg["self_condition"])
+    return load(pre, H.net_state(golden_meta[f"keys/{name}"], c["seed"] if seed is None else seed, regime))
+
+
+def north_star(out, ref, flags):
+    """max-abs <= 1e-2 on the denoised adjacency; thresholded agreement >= 99.9 % away from the boundary."""
+    out = out.detach().float().cpu()
+    ref = torch.as_tensor(ref).float()
+    err = float((out - ref).abs().max())
+    assert err <= 1e-2, f"max abs err {err:.4g}"          # the contract (BASELINE.json north_star)
+    assert err <= 2e-3, f"max abs err {err:.4g} regressed"  # engineering bound: measured 2e-5 .. 4e-4
+    valid = (flags[:, :, None] * flags[:, None, :]) > 0
+    sure = valid & (ref.abs() > 1e-2)
+    agree = float(((out > 0) == (ref > 0))[sure].float().mean()) if sure.any() else 1.0
+    assert agree >= 0.999, agree
+    return err
+
+
+@pytest.mark.parametrize("name", list(NET_CASES))
+def test_network_and_precond(S, golden, golden_meta, name, monkeypatch):
+    c = NET_CASES[name]
+    for regime in c["regimes"]:
+        pre = build_precond(S, name, golden_meta, regime)
+        for si in range(len(c["sigmas"])):
+            flags, x, sig, sc = H.net_inputs(c, si)
+            c_noise = sig.log() / 4
+            key = f"net/{name}/{regime}/s{si}"
+            outs = {
+                "F_nosc": pre.model(x.to(DEV), flags.to(DEV), c_noise.to(DEV), None),
+                "F_sc": pre.model(x.to(DEV), flags.to(DEV), c_noise.to(DEV), sc.to(DEV)),
+            }
+            for coin, u in (("coin1", 0.25), ("coin0", 0.75)):
+                monkeypatch.setattr(np.random, "rand", lambda u=u: u)
+                outs[f"D_{coin}"] = pre(x.to(DEV), flags.to(DEV), sig.to(DEV))
+                monkeypatch.undo()
+            pre.assert_symmetric()
+            for k, out in outs.items():
+                ref = golden[f"{key}/{k}"]
+                assert float((out - out.transpose(-1, -2)).abs().max()) == 0.0  # exactly symmetric
+                if regime == "init" and k.startswith("D_"):
+                    north_star(out, ref, flags)
+                elif regime == "init":
+                    rel_close(out, ref, 2e-2, 3e-3)
+                else:
+                    rel_close(out, ref, 6e-2, 8e-3)
+
+
+def test_per_sample_sigma_matches_uniform_path(S, golden_meta):
+    """labels_uniform (one conditioning row for the batch) and the per-sample path agree exactly."""
+    pre = build_precond(S, "ego60", golden_meta, "init")
+    c = NET_CASES["ego60"]
+    flags, x, _, _ = H.net_inputs(c, 1)
+    sig = torch.full((c["B"],), 0.7)
+    np.random.seed(0)
+    a = pre(x.to(DEV), flags.to(DEV), sig.to(DEV))
+    np.random.seed(0)
+    b = pre(x.to(DEV), flags.to(DEV), torch.tensor([0.7], device=DEV).expand(c["B"]))
+    assert torch.equal(a, b)
+
+
+# ---------------------------------------------------------------------------------------------
+def test_heun_kernels_match_oracle_formulas(S):
+    import swingnn_amd._lib as L
+    from swingnn_amd import engine as E
+    B, N = 3, 24
+    flags = filler.node_flags("f", B, N, 4, 20, 1)
+    x = filler.sym_adj("x", B, N, flags, 1, 3.0)
+    raw = filler.normalish("raw", (B, N, N), 2)
+    den = filler.sym_adj("den", B, N, flags, 3)
+    den2 = filler.sym_adj("den2", B, N, flags, 4)
+    t_hat, coef, h, t_prime = 2.5, 0.8, -0.4, 2.1
+    xh_ref = O.mask_adjs(x + coef * O.sym_noise_from_raw(raw), flags)
+    d_ref = O.mask_adjs((1 / t_hat) * xh_ref - (1 / t_hat) * den, flags)
+    xp_ref = xh_ref + h * d_ref
+    dp_ref = (1 / t_prime) * xp_ref - (1 / t_prime) * den2
+    xn_ref = O.mask_adjs(xh_ref + h * (0.5 * d_ref + 0.5 * dp_ref), flags)
+    g = lambda t: t.to(DEV).contiguous()
+    fl, xd, rawd, dend, den2d = g(flags), g(x), g(raw), g(den), g(den2)
+    xh, xp, dc, xn = (torch.empty_like(xd) for _ in range(4))
+    sp = E.stream_ptr()
+    L.check(L.lib.swg_heun_churn(B, N, xd.data_ptr(), rawd.data_ptr(), fl.data_ptr(), coef, xh.data_ptr(), sp), "churn")
+    L.check(L.lib.swg_heun_euler(B, N, xh.data_ptr(), dend.data_ptr(), fl.data_ptr(), t_hat, h, 0, dc.data_ptr(),
+                                 xp.data_ptr(), sp), "euler")
+    L.check(L.lib.swg_heun_correct(B, N, xh.data_ptr(), xp.data_ptr(), dc.data_ptr(), den2d.data_ptr(), fl.data_ptr(),
+                                   t_prime, h, xn.data_ptr(), sp), "correct")
+    for out, ref in ((xh, xh_ref), (dc, d_ref), (xp, xp_ref), (xn, xn_ref)):
+        assert H.max_abs(out.cpu(), ref) <= 2e-6 * max(1.0, float(ref.abs().max()))
+    acc = torch.zeros(1, device=DEV)
+    L.check(L.lib.swg_sym_check(B, N, xn.data_ptr(), acc.data_ptr(), sp), "sym")
+    assert float(acc.item()) == 0.0
+    bad = xn.clone()
+    bad[0, 1, 2] += 1.0
+    L.check(L.lib.swg_sym_check(B, N, bad.data_ptr(), acc.data_ptr(), sp), "sym")
+    assert abs(float(acc.item()) - 2.0) < 1e-5
+    # ragged N (not a multiple of the 32-tile) and an empty graph
+    B2, N2 = 2, 37
+    fl2 = torch.zeros(B2, N2)
+    fl2[0, :9] = 1
+    a = filler.normalish("a", (B2, N2, N2), 9)
+    ad = g(a)
+    L.check(L.lib.swg_mask_adjs(B2, N2, ad.data_ptr(), g(fl2).data_ptr(), sp), "mask")
+    assert torch.equal(ad.cpu(), O.mask_adjs(a, fl2))
+
+
+@pytest.mark.parametrize("name", list(SAMPLER_CASES))
+def test_edm_sampler(S, golden, golden_meta, name):
+    c = SAMPLER_CASES[name]
+    nc = NET_CASES[c["net"]]
+    cfg = nc["cfg"]
+    pre = build_precond(S, c["net"], golden_meta, c["regime"], seed=c["seed"])
+    smp = S.EDMSampler(num_steps=c["steps"], clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
+                       clip_samples_scope="x_0", self_condition=cfg["self_condition"], dev=DEV)
+    assert np.allclose(smp.sigma_steps.numpy(), golden[f"sampler/{name}/sigma_steps"], rtol=1e-12)
+    flags = filler.node_flags("flags", c["B"], cfg["img_size"], c["n_lo"], c["n_hi"], c["seed"])
+    gt = filler.sym_adj("gt", c["B"], cfg["img_size"], flags, c["seed"]).sign() if c["sanity"] else None
+    # identical noise: the reference drew everything from the CPU generator in this order
+    torch.manual_seed(c["seed"])
+    np.random.seed(c["seed"])
+    smp._randn_like = lambda x: torch.randn(x.shape).to(x.device)
+    final, interim = smp.sample(pre, flags.to(DEV), sanity_check_gt_adjs=None if gt is None else gt.to(DEV),
+                                flag_interim_adjs=True, max_num_interim_adjs=5)
+    ref = torch.from_numpy(golden[f"sampler/{name}/final"])
+    assert final.device.type == "cpu" and interim.shape == golden[f"sampler/{name}/interim"].shape
+    if c["sanity"]:
+        assert H.max_abs(final, gt) < 1e-5  # known-answer: perfect denoiser reproduces the data
+        assert H.max_abs(final, ref) < 1e-5
+        return
+    err = float((final - ref).abs().max())
+    assert err <= 1e-2, f"final sample max abs err {err:.4g}"
+    thr = O.threshold_adj(final, flags)
+    thr_ref = torch.from_numpy(golden[f"sampler/{name}/thresholded"])
+    valid = (flags[:, :, None] * flags[:, None, :]) > 0
+    sure = valid & (ref.abs() > 1e-2)
+    assert float((thr == thr_ref)[sure].float().mean()) >= 0.999
+    print(f"{name}: max err {err:.3g}, raw thresholded agreement {float((thr == thr_ref)[valid].float().mean()):.5f}")
