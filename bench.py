@@ -1,0 +1,192 @@
+"""Headline benchmark: sampled graphs/sec, EDM stochastic Heun sampling, grid (361 nodes) dim-96.
+
+    python bench.py --gpus N --steps K --warmup W            (N=1)
+    python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N --steps K --warmup W
+
+One "step" = one full EDMSampler.sample() call (256 Heun steps = 511 preconditioner calls, expected 766.5
+network passes) on a batch of `--batch` synthetic grid-size graphs per GPU.  Ranks are independent
+(sampling shards as independent graphs: no data-path collective); value = graphs all ranks sampled /
+max-over-ranks wall time.  Weights are random-init (reference init under seed 1234), inputs synthetic.
+
+Extra objects in the JSON line:
+  roofline     - dominant kernel of the run, timed live with HIP events by the library's profiler
+                 (swg_prof_*) over a short profiled replay of the same workload after the timed region
+  cpu_baseline - the CPU oracle (torch fp32, `oracle/`, kind "port") timed on this box's host cores on a
+                 bounded sample (few Heun steps, batch 1), extrapolated linearly in steps
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+import numpy as np
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+CONFIGS = {
+    # config/edm_swin_gnn/grid_edm_swin_gnn_80.yaml with --feature_dims 96 (README.md:69-90)
+    "grid": dict(img_size=384, patch_size=4, embed_dim=96, depths=[1, 1, 3, 1], window_size=6, n_nodes=(361, 361)),
+    "dd": dict(img_size=512, patch_size=4, embed_dim=96, depths=[1, 1, 3, 1], window_size=8, n_nodes=(100, 500)),
+    "community_small": dict(img_size=24, patch_size=3, embed_dim=96, depths=[4, 4, 6], window_size=24, n_nodes=(12, 20)),
+    "ego_small": dict(img_size=24, patch_size=3, embed_dim=60, depths=[4, 4, 6], window_size=24, n_nodes=(4, 18)),
+}
+HBM_PEAK_GBS = 8000.0        # MI355X_MICROARCH.md: 8 TB/s spec
+MFMA_BF16_PEAK_TFLOPS = 2500.0  # dense bf16
+
+
+def make_flags(cfg, B, rng):
+    lo, hi = cfg["n_nodes"]
+    n = rng.integers(lo, hi + 1, size=B)
+    return (torch.arange(cfg["img_size"])[None, :] < torch.from_numpy(n)[:, None]).to(torch.float32)
+
+
+def build_model(cfg, dev):
+    import swingnn_amd as S
+    torch.manual_seed(1234)
+    net = S.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
+                    depths=cfg["depths"], num_heads=[3, 6, 12, 24], window_size=cfg["window_size"], mlp_ratio=4.,
+                    drop_rate=0., attn_drop_rate=0., drop_path_rate=0.0, self_condition=True)
+    return S.Precond("edm", net, True).to(dev).eval()
+
+
+def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
+    """Oracle (CPU port of the reference path) on a bounded sample: batch 1, few Heun steps."""
+    from oracle import swingnn_ref as O
+    ocfg = dict(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
+                depths=cfg["depths"], num_heads=[3, 6, 12, 24], window_size=cfg["window_size"], self_condition=True)
+    sd = {k: v.detach().cpu() for k, v in state_dict.items()}
+    flags = make_flags(cfg, 1, np.random.default_rng(7))
+    calls = []
+
+    def den(x, fl, sig, sc):
+        t0 = time.perf_counter()
+        D = O.precond_forward(sd, ocfg, x, fl, sig, np.random.rand() < 0.5)
+        calls.append(time.perf_counter() - t0)
+        return D
+
+    torch.manual_seed(7)
+    np.random.seed(7)
+    with torch.no_grad():
+        den(O.gen_init_sample(flags) * 80.0, flags, torch.full((1,), 80.0), None)  # warm-up call
+        per_call = calls[-1]
+        steps = int(max(2, min(8, seconds_budget / max(per_call * 3.0, 1e-3))))
+        calls.clear()
+        t0 = time.perf_counter()
+        O.edm_sample(den, flags, num_steps=steps, self_condition=True)
+        dt = time.perf_counter() - t0
+    # a full sample makes 511 preconditioner calls; the bounded run made 2*steps-1
+    full = dt * 511.0 / (2 * steps - 1)
+    return dict(value=1.0 / full, unit="graphs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle/swingnn_ref.py edm_sample, batch 1, {steps} of 256 Heun steps ({2 * steps - 1} "
+                       f"preconditioner calls in {dt:.1f} s), extrapolated linearly to 511 calls")
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=2)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=16, help="graphs per GPU per sample() call")
+    ap.add_argument("--config", default="grid", choices=list(CONFIGS))
+    ap.add_argument("--num-steps", type=int, default=256, help="Heun steps (256 = the shipped configs)")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    args = ap.parse_args()
+
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+    if world > 1:
+        import torch.distributed as dist
+        dist.init_process_group("nccl", device_id=dev)
+
+    import swingnn_amd as S
+    from swingnn_amd import prof
+
+    cfg = CONFIGS[args.config]
+    model = build_model(cfg, dev)
+    sampler = S.EDMSampler(num_steps=args.num_steps, clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
+                           clip_samples_scope="x_0", self_condition=True, dev=dev)
+    seed = 1234 + rank  # utils/arg_parser.py:254-255
+    torch.manual_seed(seed)
+    np.random.seed(seed)
+    flags = make_flags(cfg, args.batch, np.random.default_rng(seed)).to(dev)
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            dist.barrier()
+            torch.cuda.synchronize()
+
+    with torch.no_grad():
+        for _ in range(args.warmup):
+            sampler.sample(model, flags)
+        barrier()
+        t0 = time.perf_counter()
+        for _ in range(args.steps):
+            out = sampler.sample(model, flags)
+        barrier()
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    if world > 1:
+        t = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+
+    result = None
+    if rank == 0:
+        # ---- live per-kernel timing (HIP events inside the library) on a short replay of the same workload ----
+        short = S.EDMSampler(num_steps=4, clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
+                             clip_samples_scope="x_0", self_condition=True, dev=dev)
+        with torch.no_grad(), prof.profiled():
+            short.sample(model, flags)
+        kern = prof.read()
+        total_ms = sum(k["ms"] for k in kern.values())
+        name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+        avg_s = dom["ms"] * 1e-3 / dom["launches"]
+        ai = dom["flops"] / max(dom["bytes"], 1.0)
+        if ai >= MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+            achieved = dom["flops"] / dom["launches"] / avg_s / 1e12
+            roof = dict(bound="mfma", achieved=achieved, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                        frac=achieved / MFMA_BF16_PEAK_TFLOPS)
+        else:
+            achieved = dom["bytes"] / dom["launches"] / avg_s / 1e9
+            roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
+        roof.update(kernel=name, traffic=None, avg_launch_us=avg_s * 1e6, launches=dom["launches"],
+                    share_of_gpu_time=dom["ms"] / total_ms,
+                    tflops=dom["flops"] / (dom["ms"] * 1e-3) / 1e12, algorithmic_GBs=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
+                    kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                                     tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                     GBs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in kern.items()},
+                    sample="4-step sample() replay, same batch, profiler on (untimed)")
+        graphs = args.batch * world * args.steps
+        result = {
+            "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.config == "grid"
+            else f"sampled graphs/sec, EDM {args.config}",
+            "value": graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+            "dtype": "bf16 MFMA operands, fp32 accumulate/state", "data": "synthetic",
+            "config": {"workload": f"{args.config} EDM Heun sampling: N={cfg['img_size']}, nodes {cfg['n_nodes']}, "
+                                   f"dim-{cfg['embed_dim']}, depths {cfg['depths']}, window {cfg['window_size']}, "
+                                   f"{args.num_steps} steps, self_cond, random-init weights",
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "parallelism": f"independent replicas x{world} (batch-sharded, no collective)"},
+            "roofline": roof,
+        }
+        if not args.no_cpu_baseline:
+            result["cpu_baseline"] = cpu_baseline(cfg, model.state_dict())
+            result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+    if world > 1:
+        dist.barrier()
+        dist.destroy_process_group()
+    if rank == 0:
+        print(json.dumps(result))
+
+
+if __name__ == "__main__":
+    main()

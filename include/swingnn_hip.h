@@ -149,6 +149,12 @@ int swg_readout_sym_precond_fwd(const swg_net* net, int32_t B, const float* tok,
                                 const float* node_flags, const float* coef, float* out, float* sym_err, void* ws,
                                 size_t ws_bytes, void* stream);
 
+/* nn.Linear forward on bf16 operands (the building block behind qkv/proj/fc1/fc2/reduction/pre/post_linear):
+ * out[M,N] = act(a[M,Kp] @ w[N,Kp]^T + bias) + residual; a, w bf16 (K zero-padded to Kp, a multiple of 32);
+ * exactly one of out_f32 / out_bf16; residual (fp32, stride ldo) only with out_f32; act 0 none, 1 exact GELU. */
+int swg_linear_bf16(int32_t M, int32_t N, int32_t Kp, const void* a, int32_t lda, const void* w, const float* bias,
+                    int32_t act, const float* residual, float* out_f32, void* out_bf16, int32_t ldo, void* stream);
+
 /* ---- EDM Heun sampler updates (runner/mcmc_sampler/edm.py:168-217, shipped defaults) -- */
 /* :174-176  x_hat = mask(x + noise_coef * sym(raw)),  sym(raw) = triu(raw,1) + triu(raw,1)^T
  * (utils/graph_utils.py:113-119).  All tensors [B,N,N] fp32. */
@@ -165,6 +171,16 @@ int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_pr
 /* utils/graph_utils.py:5-38 (in place) and :89-94 (acc += sum|a - a^T|, no host sync) */
 int swg_mask_adjs(int32_t B, int32_t N, float* a, const float* node_flags, void* stream);
 int swg_sym_check(int32_t B, int32_t N, const float* a, float* acc, void* stream);
+
+/* ---- measurement aid (no counterpart in the reference) ---------------------------------- *
+ * When enabled, every internal kernel launch is bracketed by HIP events on its stream and its
+ * algorithmic FLOPs / bytes are tallied per kernel.  swg_prof_read synchronises the recorded events.
+ * Keep it off under HIP graph capture and inside timed throughput regions. */
+int swg_prof_enable(int32_t on);
+int swg_prof_reset(void);
+int swg_prof_kernels(void);
+const char* swg_prof_name(int32_t kid);
+int swg_prof_read(int32_t kid, double* ms, double* flops, double* bytes, int64_t* launches);
 
 #ifdef __cplusplus
 }

@@ -69,11 +69,18 @@ SYMBOLS = {
     "swg_patch_merge_fwd": (C.c_int, [C.POINTER(SwgMerge), _i32, _fp, _fp, _fp, _sz, _fp]),
     "swg_patch_expand_fwd": (C.c_int, [C.POINTER(SwgBreakup), _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
     "swg_readout_sym_precond_fwd": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_linear_bf16": (C.c_int, [_i32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _fp, _fp, _fp, _i32, _fp]),
     "swg_heun_churn": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _f, _fp, _fp]),
     "swg_heun_euler": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _f, _f, _i32, _fp, _fp, _fp]),
     "swg_heun_correct": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp]),
     "swg_mask_adjs": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
     "swg_sym_check": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
+    "swg_prof_enable": (C.c_int, [_i32]),
+    "swg_prof_reset": (C.c_int, []),
+    "swg_prof_kernels": (C.c_int, []),
+    "swg_prof_name": (C.c_char_p, [_i32]),
+    "swg_prof_read": (C.c_int, [_i32, C.POINTER(C.c_double), C.POINTER(C.c_double), C.POINTER(C.c_double),
+                                C.POINTER(C.c_int64)]),
 }
 
 

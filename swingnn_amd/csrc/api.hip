@@ -214,6 +214,16 @@ size_t swg_workspace_bytes(const swg_net* net, int32_t B) {
   return pl.persistent + pl.scratch + 4096;
 }
 
+int swg_linear_bf16(int32_t M, int32_t N, int32_t Kp, const void* a, int32_t lda, const void* w, const float* bias,
+                    int32_t act, const float* residual, float* out_f32, void* out_bf16, int32_t ldo, void* stream) {
+  if (!a || !w || (!out_f32 && !out_bf16)) return SWG_E_NULL;
+  if (M <= 0 || N <= 0) return SWG_E_SHAPE;
+  GemmEpi e = {};
+  e.bias = bias; e.act = act; e.residual = residual; e.ldr = ldo; e.out_f32 = out_f32; e.out_bf16 = (bf16*)out_bf16;
+  e.ldo = ldo; e.n_store = N;
+  return launch_gemm((const bf16*)a, lda, (const bf16*)w, M, N, Kp, e, (hipStream_t)stream);
+}
+
 int swg_noise_embed(const swg_net* net, int32_t Bc, const float* c_noise, float* cond, void* ws, size_t ws_bytes,
                     void* stream) {
   if (Bc <= 0) return SWG_E_SHAPE;

@@ -54,28 +54,29 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lg = lane >> 4;
 
-  // global -> register staging
-  uint4 rx[LD_PER_THR], rw[LD_PER_THR];
-  auto g_load = [&](int kt) {
+  // global -> register staging (plain unrolled code: arrays captured by lambdas end up in scratch memory)
+  bf16x8 rx[LD_PER_THR], rw[LD_PER_THR];
+  const bf16* gx[LD_PER_THR];
+  const bf16* gw[LD_PER_THR];
+  int soff[LD_PER_THR];
 #pragma unroll
-    for (int i = 0; i < LD_PER_THR; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / CH, ch = id - row * CH;
-      const int gm = min(m0 + row, M - 1), gn = min(n0 + row, N - 1);
-      rx[i] = *reinterpret_cast<const uint4*>(A + (size_t)gm * lda + kt * BK + ch * 8);
-      rw[i] = *reinterpret_cast<const uint4*>(W + (size_t)gn * Kp + kt * BK + ch * 8);
-    }
-  };
-  auto s_store = [&](int buf) {
-#pragma unroll
-    for (int i = 0; i < LD_PER_THR; ++i) {
-      const int id = tid + i * 256;
-      const int row = id / CH, ch = id - row * CH;
-      const int off = row * BK + Swz<BK>::chunk(row, ch) * 8;
-      *reinterpret_cast<uint4*>(&sX[buf][off]) = rx[i];
-      *reinterpret_cast<uint4*>(&sW[buf][off]) = rw[i];
-    }
-  };
+  for (int i = 0; i < LD_PER_THR; ++i) {
+    const int id = tid + i * 256;
+    const int row = id / CH, ch = id - row * CH;
+    gx[i] = A + (size_t)min(m0 + row, M - 1) * lda + ch * 8;
+    gw[i] = W + (size_t)min(n0 + row, N - 1) * Kp + ch * 8;
+    soff[i] = row * BK + Swz<BK>::chunk(row, ch) * 8;
+  }
+#define G_LOAD(KT)                                                             \
+  _Pragma("unroll") for (int i = 0; i < LD_PER_THR; ++i) {                     \
+    rx[i] = *reinterpret_cast<const bf16x8*>(gx[i] + (KT) * BK);                \
+    rw[i] = *reinterpret_cast<const bf16x8*>(gw[i] + (KT) * BK);                \
+  }
+#define S_STORE(BUF)                                                           \
+  _Pragma("unroll") for (int i = 0; i < LD_PER_THR; ++i) {                     \
+    *reinterpret_cast<bf16x8*>(&sX[BUF][soff[i]]) = rx[i];                      \
+    *reinterpret_cast<bf16x8*>(&sW[BUF][soff[i]]) = rw[i];                      \
+  }
 
   f32x4 acc[4][4];  // [nt][mt]
 #pragma unroll
@@ -83,22 +84,32 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
+  // fragment read offsets (elements) of this lane, per 32-deep k-step
+  int fwo[4][KSTEPS], fxo[4][KSTEPS];
+#pragma unroll
+  for (int t = 0; t < 4; ++t)
+#pragma unroll
+    for (int ks = 0; ks < KSTEPS; ++ks) {
+      const int rw_ = wn * 64 + t * 16 + l15;
+      const int rx_ = wm * 64 + t * 16 + l15;
+      fwo[t][ks] = rw_ * BK + Swz<BK>::chunk(rw_, ks * 4 + lg) * 8;
+      fxo[t][ks] = rx_ * BK + Swz<BK>::chunk(rx_, ks * 4 + lg) * 8;
+    }
+
   const int nk = Kp / BK;
-  g_load(0);
-  s_store(0);
+  G_LOAD(0);
+  S_STORE(0);
   __syncthreads();
   for (int kt = 0; kt < nk; ++kt) {
     const int buf = kt & 1;
-    if (kt + 1 < nk) g_load(kt + 1);
+    if (kt + 1 < nk) { G_LOAD(kt + 1); }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       bf16x8 fw[4], fx[4];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
-        const int rw_ = wn * 64 + t * 16 + l15;
-        const int rx_ = wm * 64 + t * 16 + l15;
-        fw[t] = *reinterpret_cast<const bf16x8*>(&sW[buf][rw_ * BK + Swz<BK>::chunk(rw_, ks * 4 + lg) * 8]);
-        fx[t] = *reinterpret_cast<const bf16x8*>(&sX[buf][rx_ * BK + Swz<BK>::chunk(rx_, ks * 4 + lg) * 8]);
+        fw[t] = *reinterpret_cast<const bf16x8*>(&sW[buf][fwo[t][ks]]);
+        fx[t] = *reinterpret_cast<const bf16x8*>(&sX[buf][fxo[t][ks]]);
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
@@ -106,9 +117,11 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
         for (int mt = 0; mt < 4; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[nt][mt], 0, 0, 0);
     }
-    if (kt + 1 < nk) s_store(buf ^ 1);
+    if (kt + 1 < nk) { S_STORE(buf ^ 1); }
     __syncthreads();
   }
+#undef G_LOAD
+#undef S_STORE
 
   // epilogue: lane owns token m = ... + l15 and features n = ... + 4*lg + {0..3}
 #pragma unroll
@@ -152,6 +165,9 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   if (ee.n_store < N || ee.n_store > ee.ldo || ee.n_store % 4) return SWG_E_SHAPE;
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(ee.n_store, BN);
   const int nwg = tiles_m * tiles_n;
+  const double osz = ee.out_f32 ? 4.0 : 2.0;
+  SwgProfScope ps(KID_GEMM, 2.0 * M * (double)N * Kp,
+                  2.0 * M * Kp + 2.0 * N * (double)Kp + osz * M * (double)N + (ee.residual ? 4.0 * M * (double)N : 0.0), s);
   if (Kp % 64 == 0)
     hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
   else

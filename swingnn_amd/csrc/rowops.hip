@@ -149,6 +149,11 @@ static int launch_row(const RowArgs& a, int chunks, hipStream_t s) {
   if (a.rows <= 0) return 0;
   if (a.C % 4) return SWG_E_SHAPE;
   RowGeom geo = row_geom(chunks);
+  static const int kid_of[5] = {KID_ROW_COND_LN, KID_ROW_MERGE_LN, KID_ROW_CONCAT, KID_ROW_LN_F32, KID_ROW_BREAKUP_LN};
+  const double el = (double)a.rows * a.C;
+  double bytes = 4.0 * el + (a.out_bf16 ? 2.0 * el : 0.0) + ((a.out_f32 && MODE != ROW_COND_LN) ? 4.0 * el : 0.0);
+  if (MODE == ROW_COND_LN && a.out_f32 && a.cond) bytes += 4.0 * el;
+  SwgProfScope ps(kid_of[MODE], 0.0, bytes, s);
 #define CALL(LN, VV)                                                                            \
   hipLaunchKernelGGL((k_row<LN, VV, MODE>), dim3(cdiv(a.rows, 256 / LN)), dim3(256), 0, s, a)
   SWG_ROW_DISPATCH(geo, CALL);
@@ -226,6 +231,7 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ W, 
 int launch_gemv_rows(const float* W, const float* bias, const float* x, int Bx, int N, int K, int act, float* out,
                      hipStream_t s) {
   if (K % 4 || K > 512) return SWG_E_UNSUPPORTED;
+  SwgProfScope ps(KID_GEMV, 2.0 * Bx * (double)N * K, 4.0 * N * (double)K + 4.0 * Bx * (K + N), s);
   hipLaunchKernelGGL(k_gemv_rows, dim3(cdiv(N, 4)), dim3(256), 0, s, W, bias, x, Bx, N, K, act, out);
   SWG_LAUNCH_CHECK();
   return 0;
@@ -242,6 +248,7 @@ __global__ void k_pos_embed(const float* __restrict__ labels, int Bc, const floa
 }
 
 int launch_pos_embed(const float* labels, int Bc, const float* freqs, int nf, float* out, hipStream_t s) {
+  SwgProfScope ps(KID_POS_EMBED, 0.0, 8.0 * Bc * nf, s);
   hipLaunchKernelGGL(k_pos_embed, dim3(cdiv(Bc * nf, 256)), dim3(256), 0, s, labels, Bc, freqs, nf, out);
   SWG_LAUNCH_CHECK();
   return 0;
@@ -269,6 +276,7 @@ __global__ void k_edm_coef(const float* __restrict__ labels, int B, int uniform,
 }
 
 int launch_edm_coef(const float* labels, int B, int uniform, int mode, float* coef, float* c_noise, hipStream_t s) {
+  SwgProfScope ps(KID_EDM_COEF, 0.0, 24.0 * B, s);
   hipLaunchKernelGGL(k_edm_coef, dim3(cdiv(B, 64)), dim3(64), 0, s, labels, B, uniform, mode, coef, c_noise);
   SWG_LAUNCH_CHECK();
   return 0;
@@ -375,6 +383,8 @@ int launch_patch_embed(const swg_net* net, int B, const float* x, const float* s
   const int hp = net->N / net->p;
   const int rows = B * hp * hp;
   RowGeom geo = row_geom(net->C0 / 4);
+  SwgProfScope ps(KID_PATCH_EMBED, 2.0 * rows * (double)net->C0 * kin,
+                  4.0 * B * (double)net->N * net->N * (sc ? 2 : 1) + 4.0 * rows * (double)net->C0, s);
 #define CALL(LN, VV) hipLaunchKernelGGL((k_patch_embed<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256), 0, s, a)
   SWG_ROW_DISPATCH(geo, CALL);
 #undef CALL
@@ -460,6 +470,8 @@ int launch_final_readout(const swg_net* net, int B, const float* tok, float* F, 
   const int hp = net->N / net->p;
   const int rows = B * hp * hp;
   RowGeom geo = row_geom(net->C0 / 4);
+  SwgProfScope ps(KID_READOUT, 2.0 * rows * (double)net->C0 * net->p * net->p,
+                  4.0 * rows * (double)net->C0 + 4.0 * B * (double)net->N * net->N, s);
 #define CALL(LN, VV) hipLaunchKernelGGL((k_final_readout<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256), 0, s, a)
   SWG_ROW_DISPATCH(geo, CALL);
 #undef CALL
@@ -507,8 +519,10 @@ __global__ __launch_bounds__(256) void k_sym_precond(int N, const float* __restr
       if (m) {
         const float sym = 0.5f * (F[base + (size_t)r * N + c] + tF[tx][k]);
         const float xv = x ? x[base + (size_t)r * N + c] : 0.f;
-        v = c_skip * xv + c_out * sym;
-        if (sym_err) err += fabsf(v - (c_skip * tX[tx][k] + c_out * sym));
+        // explicit fma on both sides: D[r][c] and D[c][r] must round identically for the check to be exact
+        const float cs = __fmul_rn(c_out, sym);
+        v = __fmaf_rn(c_skip, xv, cs);
+        if (sym_err) err += fabsf(v - __fmaf_rn(c_skip, tX[tx][k], cs));
       }
       out[base + (size_t)r * N + c] = v;
     }
@@ -522,6 +536,7 @@ __global__ __launch_bounds__(256) void k_sym_precond(int N, const float* __restr
 int launch_sym_precond(int B, int N, const float* F, const float* x, const float* flags, const float* coef, float* out,
                        float* sym_err, hipStream_t s) {
   dim3 grid(cdiv(N, 32), cdiv(N, 32), B);
+  SwgProfScope ps(KID_SYM_PRECOND, 0.0, 4.0 * B * (double)N * N * (x ? 3 : 2), s);
   hipLaunchKernelGGL(k_sym_precond, grid, dim3(256), 0, s, N, F, x, flags, coef, out, sym_err);
   SWG_LAUNCH_CHECK();
   return 0;
@@ -632,6 +647,7 @@ int swg_heun_churn(int32_t B, int32_t N, const float* x, const float* raw_noise,
                    float noise_coef, float* x_hat, void* stream) {
   if (!x || !raw_noise || !node_flags || !x_hat) return SWG_E_NULL;
   if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  SwgProfScope ps(KID_HEUN, 0.0, 12.0 * B * (double)N * N, (hipStream_t)stream);
   hipLaunchKernelGGL(k_heun_churn, dim3(cdiv(N, 32), cdiv(N, 32), B), dim3(256), 0, (hipStream_t)stream, N, x,
                      raw_noise, node_flags, noise_coef, x_hat);
   SWG_LAUNCH_CHECK();
@@ -643,6 +659,7 @@ int swg_heun_euler(int32_t B, int32_t N, const float* x_hat, const float* denois
   if (!x_hat || !denoised || !node_flags || !x_prime) return SWG_E_NULL;
   if (B <= 0 || N <= 0 || t_hat == 0.f) return SWG_E_SHAPE;
   const size_t total = (size_t)B * N * N;
+  SwgProfScope ps(KID_HEUN, 0.0, 16.0 * total, (hipStream_t)stream);
   hipLaunchKernelGGL(k_heun_euler, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, total,
                      x_hat, denoised, node_flags, 1.0f / t_hat, h, mask_out, d_cur, x_prime);
   SWG_LAUNCH_CHECK();
@@ -655,6 +672,7 @@ int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_pr
   if (!x_hat || !x_prime || !d_cur || !denoised2 || !node_flags || !x_next) return SWG_E_NULL;
   if (B <= 0 || N <= 0 || t_prime == 0.f) return SWG_E_SHAPE;
   const size_t total = (size_t)B * N * N;
+  SwgProfScope ps(KID_HEUN, 0.0, 20.0 * total, (hipStream_t)stream);
   hipLaunchKernelGGL(k_heun_correct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
                      total, x_hat, x_prime, d_cur, denoised2, node_flags, 1.0f / t_prime, h, x_next);
   SWG_LAUNCH_CHECK();

@@ -227,6 +227,8 @@ int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shi
   const int NT = cdiv(n, 16);
   const bool fast = (hd == 32) && (ldq % 8 == 0) && (C % 8 == 0);
   dim3 grid(cdiv(total, 4)), block(256);
+  const double T = (double)B * res * res;
+  SwgProfScope ps(KID_WATTN_CORE, 4.0 * n * C * T, T * (3.0 * C * 2 + C * 2), s);
 #define WCALL(NTv)                                                                              \
   do {                                                                                          \
     if (fast) hipLaunchKernelGGL((k_wattn_core<NTv, true>), grid, block, 0, s, a);              \

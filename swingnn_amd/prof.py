@@ -1,0 +1,26 @@
+"""Python view of the library's per-kernel profiler (swg_prof_*, include/swingnn_hip.h)."""
+import ctypes as C
+from contextlib import contextmanager
+
+from . import _lib as L
+
+
+def read():
+    """{kernel name: dict(ms, flops, bytes, launches)} for kernels launched while profiling was enabled."""
+    out = {}
+    for kid in range(L.lib.swg_prof_kernels()):
+        ms, fl, by, n = C.c_double(), C.c_double(), C.c_double(), C.c_int64()
+        L.check(L.lib.swg_prof_read(kid, C.byref(ms), C.byref(fl), C.byref(by), C.byref(n)), "swg_prof_read")
+        if n.value:
+            out[L.lib.swg_prof_name(kid).decode()] = dict(ms=ms.value, flops=fl.value, bytes=by.value, launches=n.value)
+    return out
+
+
+@contextmanager
+def profiled():
+    L.lib.swg_prof_reset()
+    L.lib.swg_prof_enable(1)
+    try:
+        yield
+    finally:
+        L.lib.swg_prof_enable(0)
