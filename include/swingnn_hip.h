@@ -50,6 +50,10 @@ typedef struct swg_block {
   swg_ln ln1, ln2;
   swg_lin qkv, proj, fc1, fc2;
   const float* rpb; /* relative_position_bias_table [(2win-1)^2, heads] fp32, :84-85 */
+  /* optional derived cache for the fused LN2+fc1+GELU+fc2 kernel (C = 96 or 192): fc1/fc2 weights as a
+   * per-64-hidden-chunk LDS image in swizzled MFMA fragment order (swingnn_amd/engine.py mlp_image).
+   * NULL -> the GEMM-based path is used. */
+  const void* mlp_img;
 } swg_block;
 
 /* PatchMerging (:298-335) at input resolution res x res, input width C */

@@ -23,19 +23,19 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
 __device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
 // nn.GELU() exact erf form (model/swin_gnn/swin_gnn.py:10,15)
-// erf by Abramowitz & Stegun 7.1.26 (|abs err| <= 1.5e-7): one v_rcp, one v_exp and a degree-5 Horner chain,
-// about half the VALU work of ocml's erff; the result feeds a bf16 store (2^-9 relative), so it is exact enough.
-__device__ __forceinline__ float erf_fast(float x) {
+// Exact-erf GELU (nn.GELU(), model/swin_gnn/swin_gnn.py:10,15) evaluated as  max(x,0) - |x| * q(x),
+//   q = 0.5 * erfc(|x|/sqrt2) = 0.5 * poly5(t) * exp(-x^2/2),  t = 1 / (1 + p |x|/sqrt2)
+// (Abramowitz & Stegun 7.1.26, |abs err| <= 1.5e-7 on erf): one v_rcp, one v_exp and ten FMA-class ops, no branches.
+__device__ __forceinline__ float gelu_f(float x) {
   const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f, ax, 1.0f));
-  float p = fmaf(1.061405429f, t, -1.453152027f);
-  p = fmaf(p, t, 1.421413741f);
-  p = fmaf(p, t, -0.284496736f);
-  p = fmaf(p, t, 0.254829592f);
-  const float r = 1.0f - p * t * __expf(-ax * ax);
-  return copysignf(r, x);
+  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
+  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
+  p = fmaf(p, t, 0.5f * 1.421413741f);
+  p = fmaf(p, t, 0.5f * -0.284496736f);
+  p = fmaf(p, t, 0.5f * 0.254829592f);
+  const float e = __builtin_amdgcn_exp2f(ax * ax * (-0.5f * 1.44269504088896340736f));
+  return fmaf(-ax, p * t * e, fmaxf(x, 0.0f));
 }
-__device__ __forceinline__ float gelu_f(float v) { return 0.5f * v * (1.0f + erf_fast(v * 0.70710678118654752440f)); }
 
 // sum over a group of LANES consecutive lanes (LANES power of two <= 64)
 template <int LANES>
@@ -118,3 +118,7 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
 // wattn.hip : window attention core on a qkv buffer
 int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shift, int heads, int C, const float* rpb,
                       bf16* o, int ldo, hipStream_t s);
+// mlp_fused.hip : x_out = x + fc2(GELU(fc1(LN2(x)))) in one pass (C = 96 / 192)
+bool mlp_fused_supported(int C);
+int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
+                     const float* g, const float* b, hipStream_t s);

@@ -1,0 +1,244 @@
+// Fused MLP half of a Swin block (model/swin_gnn/swin_gnn.py:275 with Mlp :19-25):
+//     x_out = x + fc2( GELU( fc1( LayerNorm2(x) ) ) )
+// in ONE pass over the residual stream: each fp32 token row is read once and written once; the 4C-wide hidden
+// activation never leaves the register file.
+//
+// gfx950 mapping
+//  * A wavefront owns 32 tokens (two 16-token MFMA column tiles).  It loads their rows from HBM directly in
+//    MFMA operand layout (lane = token l&15, 8 consecutive channels per 32-deep k-step), computes the
+//    LayerNorm statistics with two xor-shuffles, and keeps the normalised bf16 fragments in VGPRs.
+//  * The hidden dimension is processed in chunks of 64: H^T = W1c . A^T (features on accumulator rows, tokens
+//    on lanes) -> +bias, GELU -> the accumulator registers ARE the B operand of out^T += W2c . H^T, because the
+//    k-slot permutation they imply is baked into the host-prepared W2 image.  No LDS round trip for activations.
+//  * Weights stream through LDS: the host lays W1/W2 out as a per-chunk image already in swizzled fragment order,
+//    so staging is a linear LDS-DMA copy (global_load_lds, 16 B per lane), double buffered, one barrier per chunk.
+#include "common.h"
+
+namespace {
+
+constexpr int HC = 64;  // hidden features per chunk
+
+struct MlpArgs {
+  const float* x;
+  float* out;
+  const bf16* img;   // weight image, see engine.py mlp_image()
+  const float* b1;   // [4C]
+  const float* b2;   // [C]
+  const float* g;    // LN2 weight
+  const float* b;    // LN2 bias
+  int T;
+};
+
+// 16-byte slot swizzle of a 64-byte LDS row (4 slots): conflict-free for ds_read_b128 fragment reads
+__device__ __forceinline__ int slot_swz(int row, int ch) { return ch ^ ((-(row >> 2)) & 3); }
+
+template <int C, bool KEEPX>
+__global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
+  constexpr int KS = C / 32;       // k-steps of fc1
+  constexpr int NT = C / 16;       // output feature tiles of fc2
+  constexpr int NCH = 4 * C / HC;  // hidden chunks
+  constexpr int CHUNK_ELEMS = 2 * HC * C;          // W1 part (HC x C) + W2 part (C x HC)
+  constexpr int CHUNK_BYTES = CHUNK_ELEMS * 2;
+  constexpr int DMA_PER_WAVE = CHUNK_BYTES / (4 * 1024);  // 1 KiB per wave-instruction, 4 waves
+  static_assert(CHUNK_BYTES % 4096 == 0, "chunk must be a whole number of 1-KiB pieces per wave");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // 2 x CHUNK_BYTES
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int tok0 = blockIdx.x * 128 + wave * 32;
+
+  // ---- stage chunk `hc` into LDS buffer `buf` by LDS-DMA (wave-uniform LDS base + lane*16) ----
+  auto stage = [&](int hc, int buf) {
+    const char* src = reinterpret_cast<const char*>(a.img) + (size_t)hc * CHUNK_BYTES;
+#pragma unroll
+    for (int i = 0; i < DMA_PER_WAVE; ++i) {
+      const int piece = i * 4 + wave;  // 1-KiB piece index inside the chunk
+      __builtin_amdgcn_global_load_lds(
+          (const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
+          (__attribute__((address_space(3))) void*)(smem + buf * CHUNK_BYTES + piece * 1024), 16, 0, 0);
+    }
+  };
+  stage(0, 0);
+  float* sb1 = reinterpret_cast<float*>(smem + 2 * CHUNK_BYTES);  // fc1 bias [4C] (read every chunk)
+  for (int i = tid; i < 4 * C; i += 256) sb1[i] = a.b1[i];
+
+  // ---- load the wave's 32 token rows in operand layout, LayerNorm2 in registers ----
+  bf16x8 xa[2][KS];
+  float xr[KEEPX ? 2 : 1][KEEPX ? KS : 1][8];  // fp32 rows kept for the residual add (KEEPX)
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
+    const float* row = a.x + (size_t)tok * C;
+    float v[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p0 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg);
+      const float4 p1 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg + 4);
+      v[ks][0] = p0.x; v[ks][1] = p0.y; v[ks][2] = p0.z; v[ks][3] = p0.w;
+      v[ks][4] = p1.x; v[ks][5] = p1.y; v[ks][6] = p1.z; v[ks][7] = p1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[ks][j];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 g0 = *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg);
+      const float4 g1 = *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg);
+      const float4 b1 = *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      bf16x8 f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (bf16)((v[ks][j] - mean) * rstd * gg[j] + bb[j]);
+      xa[mt][ks] = f;
+      if (KEEPX) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) xr[mt][ks][j] = v[ks][j];
+      }
+    }
+  }
+
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // fragment byte offsets inside a chunk image (this lane)
+  int w1_off[4];   // row nt*16+l15 of the W1 part, k-step 0; k-step s adds s*HC*64 bytes
+  int w2_off[NT];  // row nt*16+l15 of the W2 part, k-step 0; k-step s adds s*C*64 bytes
+#pragma unroll
+  for (int nt = 0; nt < 4; ++nt) {
+    const int r = nt * 16 + l15;
+    w1_off[nt] = (r * 4 + slot_swz(r, lg)) * 16;
+  }
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int r = nt * 16 + l15;
+    w2_off[nt] = HC * C * 2 + (r * 4 + slot_swz(r, lg)) * 16;
+  }
+
+  for (int hc = 0; hc < NCH; ++hc) {
+    const int buf = hc & 1;
+    // chunk hc has landed (LDS-DMA is only ordered by this wave's vmcnt, the compiler does not wait for it),
+    // and after the barrier every wave is done reading the other buffer
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __syncthreads();
+    if (hc + 1 < NCH) stage(hc + 1, buf ^ 1);
+    const char* cb = smem + buf * CHUNK_BYTES;
+
+    // ---- fc1: H^T[HC x 32 tokens] = W1c . A^T ; fragment reads run one k-step ahead of the MFMAs ----
+    f32x4 h[4][2];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) h[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    bf16x8 w1f[2][4];
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) w1f[0][nt] = *reinterpret_cast<const bf16x8*>(cb + w1_off[nt]);
+    bf16x8 w2f[2][NT];
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      if (ks + 1 < KS) {
+#pragma unroll
+        for (int nt = 0; nt < 4; ++nt)
+          w1f[(ks + 1) & 1][nt] = *reinterpret_cast<const bf16x8*>(cb + w1_off[nt] + (ks + 1) * (HC * 64));
+      } else {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) w2f[0][nt] = *reinterpret_cast<const bf16x8*>(cb + w2_off[nt]);
+      }
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+#pragma unroll
+        for (int mt = 0; mt < 2; ++mt)
+          h[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[ks & 1][nt], xa[mt][ks], h[nt][mt], 0, 0, 0);
+    }
+    // ---- bias + GELU; the accumulators become the B operand of fc2 (k-slot order matches the W2 image) ----
+    bf16x8 hb[2][2];  // [mt][k-step of fc2]
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const float4 bb = *reinterpret_cast<const float4*>(sb1 + hc * HC + nt * 16 + 4 * lg);
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) {
+        const int s2 = nt >> 1, o = (nt & 1) * 4;
+        hb[mt][s2][o + 0] = (bf16)gelu_f(h[nt][mt][0] + bb.x);
+        hb[mt][s2][o + 1] = (bf16)gelu_f(h[nt][mt][1] + bb.y);
+        hb[mt][s2][o + 2] = (bf16)gelu_f(h[nt][mt][2] + bb.z);
+        hb[mt][s2][o + 3] = (bf16)gelu_f(h[nt][mt][3] + bb.w);
+      }
+    }
+    // ---- fc2: out^T[C x 32 tokens] += W2c . H^T ----
+    {
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) w2f[1][nt] = *reinterpret_cast<const bf16x8*>(cb + w2_off[nt] + C * 64);
+#pragma unroll
+      for (int s2 = 0; s2 < 2; ++s2)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+          for (int mt = 0; mt < 2; ++mt)
+            acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[s2][nt], hb[mt][s2], acc[nt][mt], 0, 0, 0);
+    }
+  }
+
+  // ---- epilogue: + b2 + residual, fp32 store.  The fc2 rows of the image are ordered so that accumulator
+  // row 4*lg+r of feature tile nt = 2*ks+hh is channel 32*ks + 8*lg + 4*hh + r: exactly the channels this lane
+  // loaded at k-step ks, so the residual comes from registers (KEEPX) and a lane stores 32 contiguous bytes.
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int tok = tok0 + mt * 16 + l15;
+    if (tok >= a.T) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int ks = nt >> 1, hh = nt & 1;
+      const int c = 32 * ks + 8 * lg + 4 * hh;
+      const float4 bb = *reinterpret_cast<const float4*>(a.b2 + c);
+      float4 r4;
+      if (KEEPX) r4 = make_float4(xr[mt][ks][4 * hh], xr[mt][ks][4 * hh + 1], xr[mt][ks][4 * hh + 2], xr[mt][ks][4 * hh + 3]);
+      else r4 = *reinterpret_cast<const float4*>(a.x + (size_t)tok * C + c);
+      float4 o;
+      o.x = acc[nt][mt][0] + bb.x + r4.x;
+      o.y = acc[nt][mt][1] + bb.y + r4.y;
+      o.z = acc[nt][mt][2] + bb.z + r4.z;
+      o.w = acc[nt][mt][3] + bb.w + r4.w;
+      *reinterpret_cast<float4*>(a.out + (size_t)tok * C + c) = o;
+    }
+  }
+}
+
+}  // namespace
+
+bool mlp_fused_supported(int C) { return C == 96 || C == 192; }
+
+int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
+                     const float* g, const float* b, hipStream_t s) {
+  if (!mlp_fused_supported(C)) return SWG_E_UNSUPPORTED;
+  if (T <= 0) return 0;
+  MlpArgs a = {x, out, img, b1, b2, g, b, T};
+  const size_t lds = (size_t)2 * (2 * HC * C) * 2 + (size_t)4 * C * sizeof(float);
+  SwgProfScope ps(KID_FUSED_MLP, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
+  dim3 grid(cdiv(T, 128)), block(256);
+  static bool attr_set = false;  // dynamic LDS above 64 KiB needs an explicit opt-in (C = 192: 96 KiB)
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused<192, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       2 * (2 * HC * 192) * 2 + 4 * 192 * 4);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  if (C == 96) hipLaunchKernelGGL((k_mlp_fused<96, true>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((k_mlp_fused<192, false>), grid, block, lds, s, a);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}

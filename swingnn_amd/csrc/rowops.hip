@@ -296,50 +296,62 @@ struct EmbedArgs {
 
 template <int LANES, int V>
 __global__ __launch_bounds__(256) void k_patch_embed(EmbedArgs a) {
+  // LDS: conv weight transposed to [kin][C] (a lane reads its 4 channels as one float4 per tap) and the
+  // RPB x kin input taps of the block's tokens (broadcast reads inside a lane group).
+  extern __shared__ __attribute__((aligned(16))) float smem[];
   constexpr int RPB = 256 / LANES;
   const int hp = a.N / a.p;
   const int L = hp * hp;
-  const int row = blockIdx.x * RPB + (int)threadIdx.x / LANES;
-  const int g = threadIdx.x % LANES;
-  if (row >= a.B * L) return;
-  const int bi = row / L;
-  const int rem = row - bi * L;
-  const int Y = rem / hp, X = rem - Y * hp;
   const int pp = a.p * a.p;
   const int kin = a.in_ch * pp;
-  const int nch = a.C >> 2;
-  const float cin = a.c_in ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f;
-
-  float in[32];
-#pragma unroll
-  for (int k = 0; k < 32; ++k) {
-    in[k] = 0.f;
-    if (k < kin) {
-      const int ci = k / pp, ij = k - ci * pp;
-      const int i = ij / a.p, j = ij - i * a.p;
-      const size_t off = ((size_t)bi * a.N + (Y * a.p + i)) * a.N + (X * a.p + j);
-      const bool is_x = (!a.self_cond) || ci == a.in_ch - 1;  // cat([self_cond, x]) : last channel is x
-      if (is_x) in[k] = cin * a.x[off];
-      else if (a.sc) in[k] = a.sc[off];
-    }
+  float* sW = smem;                 // [kin][C]
+  float* sIn = smem + kin * a.C;    // [RPB][kin]
+  const int rows = a.B * L;
+  const int row0 = blockIdx.x * RPB;
+  for (int i = threadIdx.x; i < kin * a.C; i += 256) {
+    const int c = i / kin, k = i - c * kin;  // global layout [C][kin]
+    sW[k * a.C + c] = a.w[i];
   }
+  for (int i = threadIdx.x; i < RPB * kin; i += 256) {
+    const int t = i / kin, k = i - t * kin;
+    const int row = min(row0 + t, rows - 1);
+    const int bi = row / L;
+    const int rem = row - bi * L;
+    const int Y = rem / hp, X = rem - Y * hp;
+    const int ci = k / pp, ij = k - ci * pp;
+    const int ii = ij / a.p, jj = ij - ii * a.p;
+    const size_t off = ((size_t)bi * a.N + (Y * a.p + ii)) * a.N + (X * a.p + jj);
+    const bool is_x = (!a.self_cond) || ci == a.in_ch - 1;  // cat([self_cond, x]) : last channel is x
+    float v = 0.f;
+    if (is_x) v = (a.c_in ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f) * a.x[off];
+    else if (a.sc) v = a.sc[off];
+    sIn[i] = v;
+  }
+  __syncthreads();
+  const int tl = (int)threadIdx.x / LANES;
+  const int row = row0 + tl;
+  const int g = threadIdx.x % LANES;
+  if (row >= rows) return;
+  const int bi = row / L;
+  const int nch = a.C >> 2;
+
   float4 v[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     const int c = g + i * LANES;
-    v[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    if (c < nch) {
-      float o[4];
+    v[i] = (c < nch) ? *reinterpret_cast<const float4*>(a.bias + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float* in = sIn + tl * kin;
+  for (int k = 0; k < kin; ++k) {
+    const float xin = in[k];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const float* wr = a.w + (size_t)(4 * c + e) * kin;
-        float acc = a.bias[4 * c + e];
-#pragma unroll
-        for (int k = 0; k < 32; ++k)
-          if (k < kin) acc += in[k] * wr[k];
-        o[e] = acc;
+    for (int i = 0; i < V; ++i) {
+      const int c = g + i * LANES;
+      if (c < nch) {
+        const float4 w = *reinterpret_cast<const float4*>(sW + k * a.C + 4 * c);
+        v[i].x = fmaf(xin, w.x, v[i].x); v[i].y = fmaf(xin, w.y, v[i].y);
+        v[i].z = fmaf(xin, w.z, v[i].z); v[i].w = fmaf(xin, w.w, v[i].w);
       }
-      v[i] = make_float4(o[0], o[1], o[2], o[3]);
     }
   }
   float s = 0.f;
@@ -385,7 +397,9 @@ int launch_patch_embed(const swg_net* net, int B, const float* x, const float* s
   RowGeom geo = row_geom(net->C0 / 4);
   SwgProfScope ps(KID_PATCH_EMBED, 2.0 * rows * (double)net->C0 * kin,
                   4.0 * B * (double)net->N * net->N * (sc ? 2 : 1) + 4.0 * rows * (double)net->C0, s);
-#define CALL(LN, VV) hipLaunchKernelGGL((k_patch_embed<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256), 0, s, a)
+#define CALL(LN, VV)                                                                                   \
+  hipLaunchKernelGGL((k_patch_embed<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256),                   \
+                     (size_t)(kin * net->C0 + (256 / LN) * kin) * sizeof(float), s, a)
   SWG_ROW_DISPATCH(geo, CALL);
 #undef CALL
   SWG_LAUNCH_CHECK();
@@ -402,9 +416,16 @@ struct ReadoutArgs {
 
 template <int LANES, int V>
 __global__ __launch_bounds__(256) void k_final_readout(ReadoutArgs a) {
+  extern __shared__ __attribute__((aligned(16))) float smem[];  // collapsed read-out weight [C][16] (pp padded to 16)
   constexpr int RPB = 256 / LANES;
   const int hp = a.N / a.p;
   const int L = hp * hp;
+  const int pp = a.p * a.p;
+  for (int i = threadIdx.x; i < a.C * 16; i += 256) {
+    const int c = i >> 4, o = i & 15;
+    smem[i] = (o < pp) ? a.w[c * pp + o] : 0.f;
+  }
+  __syncthreads();
   const int row = blockIdx.x * RPB + (int)threadIdx.x / LANES;
   const int g = threadIdx.x % LANES;
   if (row >= a.B * L) return;
@@ -427,39 +448,38 @@ __global__ __launch_bounds__(256) void k_final_readout(ReadoutArgs a) {
       q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
   const float rstd = 1.0f / sqrtf(group_sum<LANES>(q) / (float)a.C + 1e-5f);
+  float o[16];
+#pragma unroll
+  for (int k = 0; k < 16; ++k) o[k] = 0.f;
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     const int c = g + i * LANES;
     if (c < nch) {
       const float4 gg = *reinterpret_cast<const float4*>(a.g + 4 * c);
       const float4 bb = *reinterpret_cast<const float4*>(a.b + 4 * c);
-      v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
-      v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
-      v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
-      v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
+      const float y[4] = {(v[i].x - mean) * rstd * gg.x + bb.x, (v[i].y - mean) * rstd * gg.y + bb.y,
+                          (v[i].z - mean) * rstd * gg.z + bb.z, (v[i].w - mean) * rstd * gg.w + bb.w};
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float4* wr = reinterpret_cast<const float4*>(smem + (4 * c + e) * 16);
+#pragma unroll
+        for (int k4 = 0; k4 < 4; ++k4) {
+          const float4 w = wr[k4];
+          o[4 * k4 + 0] = fmaf(y[e], w.x, o[4 * k4 + 0]); o[4 * k4 + 1] = fmaf(y[e], w.y, o[4 * k4 + 1]);
+          o[4 * k4 + 2] = fmaf(y[e], w.z, o[4 * k4 + 2]); o[4 * k4 + 3] = fmaf(y[e], w.w, o[4 * k4 + 3]);
+        }
+      }
     }
   }
-  const int pp = a.p * a.p;
   const int bi = row / L;
   const int rem = row - bi * L;
   const int Y = rem / hp, X = rem - Y * hp;
 #pragma unroll
-  for (int o = 0; o < 16; ++o) {
-    if (o < pp) {
-      float acc = 0.f;
-#pragma unroll
-      for (int i = 0; i < V; ++i) {
-        const int c = g + i * LANES;
-        if (c < nch) {
-          const float* wr = a.w + (size_t)(4 * c) * pp + o;
-          acc += (v[i].x * wr[0] + v[i].y * wr[pp]) + (v[i].z * wr[2 * pp] + v[i].w * wr[3 * pp]);
-        }
-      }
-      acc = group_sum<LANES>(acc) + a.bias;
-      if (g == (o % LANES)) {
-        const int i2 = o / a.p, j2 = o - i2 * a.p;
-        a.F[((size_t)bi * a.N + (Y * a.p + i2)) * a.N + (X * a.p + j2)] = acc;
-      }
+  for (int k = 0; k < 16; ++k) {
+    const float acc = group_sum<LANES>(o[k]) + a.bias;
+    if (k < pp && g == (k % LANES)) {
+      const int i2 = k / a.p, j2 = k - i2 * a.p;
+      a.F[((size_t)bi * a.N + (Y * a.p + i2)) * a.N + (X * a.p + j2)] = acc;
     }
   }
 }
@@ -472,7 +492,9 @@ int launch_final_readout(const swg_net* net, int B, const float* tok, float* F, 
   RowGeom geo = row_geom(net->C0 / 4);
   SwgProfScope ps(KID_READOUT, 2.0 * rows * (double)net->C0 * net->p * net->p,
                   4.0 * rows * (double)net->C0 + 4.0 * B * (double)net->N * net->N, s);
-#define CALL(LN, VV) hipLaunchKernelGGL((k_final_readout<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256), 0, s, a)
+#define CALL(LN, VV)                                                                                   \
+  hipLaunchKernelGGL((k_final_readout<LN, VV>), dim3(cdiv(rows, 256 / LN)), dim3(256),                 \
+                     (size_t)net->C0 * 16 * sizeof(float), s, a)
   SWG_ROW_DISPATCH(geo, CALL);
 #undef CALL
   SWG_LAUNCH_CHECK();

@@ -77,12 +77,51 @@ class Keep:
         return L.SwgLn(self.f32(mod.weight), self.f32(mod.bias))
 
 
+FUSED_MLP_DIMS = (96, 192)
+USE_FUSED_MLP = True
+
+
+def _slot_swizzle(t: torch.Tensor) -> torch.Tensor:
+    """t [..., rows, 4, 8]: move 16-byte chunk ch of row r to slot ch ^ ((-(r >> 2)) & 3) (the kernels'
+    slot_swz): conflict-free ds_read_b128 fragment reads from 64-byte LDS rows."""
+    rows = t.shape[-3]
+    r = torch.arange(rows, device=t.device)
+    f = (-(r >> 2)) & 3
+    idx = torch.arange(4, device=t.device)[None, :] ^ f[:, None]          # out[r, slot] = in[r, slot ^ f(r)]
+    return torch.gather(t, -2, idx[:, :, None].expand(*t.shape[:-3], rows, 4, 8))
+
+
+def mlp_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+    """Weight image of the fused MLP kernel (csrc/mlp_fused.hip): per 64-wide hidden chunk, the fc1 rows
+    [64, C] as [k-step][row][4 slots][8] followed by the fc2 columns [C, 64] as [k-step][row][4 slots][8] with
+    the k order the fc1 accumulators imply (and the fc2 rows permuted, see below): element e of chunk ch is hidden 32*s + (4ch+e if e<4 else 16+4ch+e-4)."""
+    w1, w2 = w1.detach().float(), w2.detach().float()
+    H, Cdim = w1.shape
+    nch, ks = H // 64, Cdim // 32
+    a = w1.reshape(nch, 64, ks, 4, 8).permute(0, 2, 1, 3, 4)              # [hc, s, r, ch, e]
+    a = _slot_swizzle(a.contiguous()).reshape(nch, -1)
+    ch = torch.arange(4, device=w1.device)[:, None]
+    e = torch.arange(8, device=w1.device)[None, :]
+    pi = torch.where(e < 4, 4 * ch + e, 16 + 4 * ch + e - 4).reshape(-1)  # [ch*8+e] -> k within a 32-step
+    # image row (nt*16 + i) of the fc2 part is channel 32*(nt>>1) + 8*(i>>2) + 4*(nt&1) + (i&3): the accumulator
+    # rows of a lane then coincide with the channels it loaded for fc1 (residual add from registers)
+    img_row = torch.arange(Cdim, device=w1.device)
+    nt, i = img_row // 16, img_row % 16
+    rho = 32 * (nt // 2) + 8 * (i // 4) + 4 * (nt % 2) + (i % 4)
+    b = w2[rho].reshape(Cdim, nch, 2, 32)[..., pi].reshape(Cdim, nch, 2, 4, 8).permute(1, 2, 0, 3, 4)  # [hc, s2, row, ch, e]
+    b = _slot_swizzle(b.contiguous()).reshape(nch, -1)
+    return torch.cat([a, b], dim=1).to(torch.bfloat16).contiguous()
+
+
 def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
+    img = None
+    if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
+        img = _ptr(keep(mlp_image(blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
     return L.SwgBlock(blk.dim, blk.input_resolution[0], blk.window_size, blk.shift_size, blk.num_heads, cond_off,
                       keep.ln(blk.norm1), keep.ln(blk.norm2),
                       keep.lin(blk.attn.qkv.weight, blk.attn.qkv.bias), keep.lin(blk.attn.proj.weight, blk.attn.proj.bias),
                       keep.lin(blk.mlp.fc1.weight, blk.mlp.fc1.bias), keep.lin(blk.mlp.fc2.weight, blk.mlp.fc2.bias),
-                      keep.f32(blk.attn.relative_position_bias_table))
+                      keep.f32(blk.attn.relative_position_bias_table), img)
 
 
 def merge_desc(keep: Keep, m) -> L.SwgMerge:

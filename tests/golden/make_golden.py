@@ -156,6 +156,20 @@ for name, c in SAMPLER_CASES.items():
                               flag_in_ddpm_range=True, flag_out_ddpm_range=False)
     OUT[f"sampler/{name}/thresholded"] = q.numpy().astype(np.float32)
 
+# ---- seeded initialisation fingerprint (SwinGNN._init_weights under torch.manual_seed(1234)) ----------
+for name in ("ego60", "grid192"):
+    cfg = NET_CASES[name]["cfg"]
+    torch.manual_seed(1234)
+    net = R.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=cfg["in_chans"],
+                    embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                    window_size=cfg["window_size"], mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                    drop_path_rate=0.0, self_condition=cfg["self_condition"])
+    sd = RPrecond("edm", net, cfg["self_condition"]).state_dict()
+    keys = [k for k, v in sd.items() if torch.is_floating_point(v) and not k.endswith("attn_mask")]
+    OUT[f"init/{name}/sums"] = np.array([float(sd[k].double().sum()) for k in keys])
+    OUT[f"init/{name}/abs_sums"] = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    META[f"init_keys/{name}"] = keys
+
 # ---- objective + loss (a18, a19) -----------------------------------------------------------
 B, N = 6, 24
 flags = filler.node_flags("flags", B, N, 5, 20, 3)
