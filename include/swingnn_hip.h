@@ -54,6 +54,10 @@ typedef struct swg_block {
    * per-64-hidden-chunk LDS image in swizzled MFMA fragment order (swingnn_amd/engine.py mlp_image).
    * NULL -> the GEMM-based path is used. */
   const void* mlp_img;
+  /* optional derived cache for the fused window-attention kernel (C = 96 or 192, head_dim 32, 6x6
+   * windows): per head, the Wq/Wk/Wv rows and the Wproj columns as an LDS image in swizzled MFMA fragment
+   * order (swingnn_amd/engine.py wattn_image).  NULL -> the 4-kernel path is used. */
+  const void* attn_img;
 } swg_block;
 
 /* PatchMerging (:298-335) at input resolution res x res, input width C */

@@ -1,6 +1,6 @@
 """Microbenchmark the two halves of a Swin block (swg_wattn_fwd / swg_ln_mlp_fwd) per stage geometry."""
 import ctypes as C, sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import swingnn_amd as S
 from swingnn_amd import _lib as L, engine as E
 torch.set_grad_enabled(False)

@@ -1,6 +1,6 @@
 """Microbenchmark swg_linear_bf16 per shape (run on the GPU box)."""
 import sys, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 from swingnn_amd import _lib as L, engine as E
 dev = 'cuda:0'
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16

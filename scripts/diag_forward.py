@@ -1,6 +1,6 @@
 """Diagnostic: per-case forward error of the HIP path vs golden (run on the GPU box)."""
 import json, sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import swingnn_amd as S
 from tests import helpers as H
 from tests.golden.cases import NET_CASES

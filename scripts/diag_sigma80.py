@@ -1,5 +1,5 @@
 import json, sys, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import swingnn_amd as S
 from oracle import filler, swingnn_ref as O
 from tests import helpers as H

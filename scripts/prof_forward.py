@@ -1,7 +1,7 @@
 """Per-kernel breakdown of one preconditioned network pass (run on the GPU box).
 usage: python scripts/prof_forward.py [config] [batch] [reps]"""
 import sys, time, numpy as np, torch
-sys.path.insert(0, '.')
+sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(__import__('os').path.abspath(__file__))))
 import bench
 from swingnn_amd import prof
 cfgname = sys.argv[1] if len(sys.argv) > 1 else 'grid'

@@ -28,7 +28,7 @@ class SwgBlock(C.Structure):
                 ("heads", C.c_int32), ("cond_off", C.c_int32),
                 ("ln1", SwgLn), ("ln2", SwgLn),
                 ("qkv", SwgLin), ("proj", SwgLin), ("fc1", SwgLin), ("fc2", SwgLin),
-                ("rpb", _fp), ("mlp_img", _fp)]
+                ("rpb", _fp), ("mlp_img", _fp), ("attn_img", _fp)]
 
 
 class SwgMerge(C.Structure):

@@ -61,6 +61,8 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
   if (r) return r;
   if (!x_in || !x_out || !cond) return SWG_E_NULL;
   const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C), ldq = ldq_of(C);
+  if (blk->attn_img && wattn_fused_supported(C, blk->heads, blk->win))
+    return launch_wattn_fused(blk, B, x_in, cond, cond_stride, x_out, s);
   Carver cv(ws, ws_bytes);
   float* x1 = cv.take<float>((size_t)T * C);
   bf16* xn = cv.take<bf16>((size_t)T * Cp);

@@ -21,7 +21,10 @@ static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 
-__device__ __forceinline__ float silu_f(float v) { return v / (1.0f + __expf(-v)); }
+// x * sigmoid(x) with the hardware reciprocal (1 ulp): a true IEEE division costs ~10 VALU instructions
+__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+// 1/sqrt(var + eps) of LayerNorm (v_rsq_f32, 1 ulp)
+__device__ __forceinline__ float ln_rstd(float var) { return __frsqrt_rn(var + 1e-5f); }
 // nn.GELU() exact erf form (model/swin_gnn/swin_gnn.py:10,15)
 // Exact-erf GELU (nn.GELU(), model/swin_gnn/swin_gnn.py:10,15) evaluated as  max(x,0) - |x| * q(x),
 //   q = 0.5 * erfc(|x|/sqrt2) = 0.5 * poly5(t) * exp(-x^2/2),  t = 1 / (1 + p |x|/sqrt2)
@@ -48,6 +51,28 @@ __device__ __forceinline__ float group_sum(float v) {
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
   bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
   return *reinterpret_cast<uint2*>(&v);
+}
+
+// LDS-DMA of 16 bytes per lane (global_load_lds_dwordx4): LDS destination = wave-uniform byte address + lane*16.
+// Issued through inline asm ON PURPOSE: hipcc tracks the builtin form as a pending LDS write and then puts
+// `s_waitcnt vmcnt(0)` in front of any ds_read it cannot prove disjoint from the destination (e.g. a bias vector in
+// another part of LDS), which exposes the whole transfer latency.  The caller orders the data itself:
+// `s_waitcnt vmcnt(0)` by every issuing wave, then a workgroup barrier, then the ds_reads.
+__device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_byte_addr_uniform) {
+  unsigned keep;
+  const unsigned dst = __builtin_amdgcn_readfirstlane(lds_byte_addr_uniform);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %2\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, off\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(gsrc_lane), "s"(dst)
+      : "memory");
+}
+__device__ __forceinline__ unsigned lds_addr(const void* p) {
+  return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
 
 // ---- row-kernel launch geometry: a row of `chunks` float4 is handled by LANES lanes x V chunks ----
@@ -122,3 +147,7 @@ int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shi
 bool mlp_fused_supported(int C);
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                      const float* g, const float* b, hipStream_t s);
+// wattn_fused.hip : conditioning + LN1 + QKV + window attention + proj + shortcut in one pass (C = 96 / 192)
+bool wattn_fused_supported(int C, int heads, int win);
+int launch_wattn_fused(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
+                       hipStream_t s);

@@ -12,6 +12,8 @@
 //    of tile k+1 are in flight while tile k is multiplied (one barrier per K tile).
 //  * blockIdx is remapped so that consecutive logical tiles (which share the activation row panel) land on
 //    the same XCD and hit its L2.
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
@@ -168,7 +170,8 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   const double osz = ee.out_f32 ? 4.0 : 2.0;
   SwgProfScope ps(KID_GEMM, 2.0 * M * (double)N * Kp,
                   2.0 * M * Kp + 2.0 * N * (double)Kp + osz * M * (double)N + (ee.residual ? 4.0 * M * (double)N : 0.0), s);
-  if (Kp % 64 == 0)
+  static const bool force32 = getenv("SWG_GEMM_BK32") != nullptr;
+  if (Kp % 64 == 0 && !force32)
     hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
   else
     hipLaunchKernelGGL(k_gemm_nt<32>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);

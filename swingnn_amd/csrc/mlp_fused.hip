@@ -53,9 +53,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
 #pragma unroll
     for (int i = 0; i < DMA_PER_WAVE; ++i) {
       const int piece = i * 4 + wave;  // 1-KiB piece index inside the chunk
-      __builtin_amdgcn_global_load_lds(
-          (const __attribute__((address_space(1))) void*)(src + piece * 1024 + lane * 16),
-          (__attribute__((address_space(3))) void*)(smem + buf * CHUNK_BYTES + piece * 1024), 16, 0, 0);
+      lds_dma16(src + piece * 1024 + lane * 16, lds_addr(smem) + buf * CHUNK_BYTES + piece * 1024);
     }
   };
   stage(0, 0);
@@ -90,7 +88,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
       for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
     q += __shfl_xor(q, 16, 64);
     q += __shfl_xor(q, 32, 64);
-    const float rstd = 1.0f / sqrtf(q * (1.0f / C) + 1e-5f);
+    const float rstd = ln_rstd(q * (1.0f / C));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       const float4 g0 = *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg);

@@ -101,7 +101,7 @@ __global__ __launch_bounds__(256) void k_row(RowArgs a) {
         q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
       }
     }
-    const float rstd = 1.0f / sqrtf(group_sum<LANES>(q) / (float)a.C + 1e-5f);
+    const float rstd = ln_rstd(group_sum<LANES>(q) / (float)a.C);
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const int c = g + i * LANES;
@@ -365,7 +365,7 @@ __global__ __launch_bounds__(256) void k_patch_embed(EmbedArgs a) {
       const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
       q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
-  const float rstd = 1.0f / sqrtf(group_sum<LANES>(q) / (float)a.C + 1e-5f);
+  const float rstd = ln_rstd(group_sum<LANES>(q) / (float)a.C);
   const float* crow = a.cond + (size_t)bi * a.cond_stride + a.cond_off;
 #pragma unroll
   for (int i = 0; i < V; ++i) {
@@ -447,7 +447,7 @@ __global__ __launch_bounds__(256) void k_final_readout(ReadoutArgs a) {
       const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
       q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
     }
-  const float rstd = 1.0f / sqrtf(group_sum<LANES>(q) / (float)a.C + 1e-5f);
+  const float rstd = ln_rstd(group_sum<LANES>(q) / (float)a.C);
   float o[16];
 #pragma unroll
   for (int k = 0; k < 16; ++k) o[k] = 0.f;

@@ -113,15 +113,58 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     return torch.cat([a, b], dim=1).to(torch.bfloat16).contiguous()
 
 
+FUSED_ATTN_DIMS = (96, 192)
+FUSED_ATTN_WINDOWS = (6,)
+USE_FUSED_ATTN = True
+
+
+def _rho(Cdim: int, device) -> torch.Tensor:
+    """Channel held by image row nt*16 + i of an output-feature operand: 32*(nt>>1) + 8*(i>>2) + 4*(nt&1) + (i&3),
+    i.e. accumulator row 4*lg + r of tile nt = 2*ks + hh is channel 32*ks + 8*lg + 4*hh + r -- the channels a lane
+    loaded for k-step ks, so residual adds and stores need no cross-lane movement."""
+    row = torch.arange(Cdim, device=device)
+    nt, i = row // 16, row % 16
+    return 32 * (nt // 2) + 8 * (i // 4) + 4 * (nt % 2) + (i % 4)
+
+
+def _pi(device) -> torch.Tensor:
+    """k-slot order implied by two stacked 16x16 accumulator tiles: element e of chunk ch is index
+    (4ch + e if e < 4 else 16 + 4ch + e - 4) of a 32-deep k-step."""
+    ch = torch.arange(4, device=device)[:, None]
+    e = torch.arange(8, device=device)[None, :]
+    return torch.where(e < 4, 4 * ch + e, 16 + 4 * ch + e - 4).reshape(-1)
+
+
+def wattn_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int) -> torch.Tensor:
+    """Weight image of the fused window-attention kernel (csrc/wattn_fused.hip), head_dim 32: per head the
+    Wq, Wk, Wv row slices [32, C] as [k-step][row][4 slots][8] and the Wproj column slice [C, 32] as
+    [row rho][4 slots][8] with the head-dim slot order pi."""
+    qkv_w, proj_w = qkv_w.detach().float(), proj_w.detach().float()
+    Cdim = proj_w.shape[0]
+    ks = Cdim // 32
+    dev = qkv_w.device
+    parts = []
+    for part in range(3):
+        w = qkv_w[part * Cdim:(part + 1) * Cdim].reshape(heads, 32, ks, 4, 8).permute(0, 2, 1, 3, 4)  # [h, s, d, ch, e]
+        parts.append(_slot_swizzle(w.contiguous()).reshape(heads, -1))
+    wp = proj_w[_rho(Cdim, dev)].reshape(Cdim, heads, 32)[..., _pi(dev)].reshape(Cdim, heads, 4, 8).permute(1, 0, 2, 3)
+    parts.append(_slot_swizzle(wp.contiguous()).reshape(heads, -1))
+    return torch.cat(parts, dim=1).to(torch.bfloat16).contiguous()
+
+
 def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
     img = None
+    aimg = None
+    if (USE_FUSED_ATTN and blk.dim in FUSED_ATTN_DIMS and blk.window_size in FUSED_ATTN_WINDOWS
+            and blk.dim // blk.num_heads == 32):
+        aimg = _ptr(keep(wattn_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads)))
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
         img = _ptr(keep(mlp_image(blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
     return L.SwgBlock(blk.dim, blk.input_resolution[0], blk.window_size, blk.shift_size, blk.num_heads, cond_off,
                       keep.ln(blk.norm1), keep.ln(blk.norm2),
                       keep.lin(blk.attn.qkv.weight, blk.attn.qkv.bias), keep.lin(blk.attn.proj.weight, blk.attn.proj.bias),
                       keep.lin(blk.mlp.fc1.weight, blk.mlp.fc1.bias), keep.lin(blk.mlp.fc2.weight, blk.mlp.fc2.bias),
-                      keep.f32(blk.attn.relative_position_bias_table), img)
+                      keep.f32(blk.attn.relative_position_bias_table), img, aimg)
 
 
 def merge_desc(keep: Keep, m) -> L.SwgMerge:

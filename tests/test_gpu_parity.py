@@ -97,8 +97,19 @@ def test_block_attention_half_only(S):
     L.check(L.lib.swg_wattn_fwd(C.byref(desc), c["B"], xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out.data_ptr(),
                                 ws.data_ptr(), ws.numel(), E.stream_ptr()), "swg_wattn_fwd")
     rel_close(out, ref)
-    # workspace too small / bad batch are reported, not executed
-    assert L.lib.swg_wattn_fwd(C.byref(desc), c["B"], xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out.data_ptr(),
+    # the 4-kernel path (no fused image) gives the same answer, and reports a too-small workspace / bad batch
+    saved = E.USE_FUSED_ATTN
+    E.USE_FUSED_ATTN = False
+    try:
+        desc2 = E.block_desc(keep, blk, 0)
+    finally:
+        E.USE_FUSED_ATTN = saved
+    assert desc.attn_img and not desc2.attn_img
+    out2 = torch.empty_like(xd)
+    L.check(L.lib.swg_wattn_fwd(C.byref(desc2), c["B"], xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out2.data_ptr(),
+                                ws.data_ptr(), ws.numel(), E.stream_ptr()), "swg_wattn_fwd")
+    rel_close(out2, ref)
+    assert L.lib.swg_wattn_fwd(C.byref(desc2), c["B"], xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out2.data_ptr(),
                                ws.data_ptr(), 1024, E.stream_ptr()) == -3
     assert L.lib.swg_wattn_fwd(C.byref(desc), 0, xd.data_ptr(), cond.data_ptr(), 2 * c["C"], out.data_ptr(),
                                ws.data_ptr(), ws.numel(), E.stream_ptr()) == -1
