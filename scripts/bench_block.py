@@ -23,7 +23,7 @@ for res, Cd, heads in stages:
         T = B * res * res
         x = torch.randn(B, res * res, Cd, device=dev); out = torch.empty_like(x)
         cond = torch.randn(B, 2 * Cd, device=dev) * 0.1
-        for fused in ([True, False] if Cd in E.FUSED_MLP_DIMS else [False]):
+        for fused in ([True, False] if (Cd in E.FUSED_MLP_DIMS or Cd in E.STREAM_MLP_HC) else [False]):
             E.USE_FUSED_MLP = fused
             keep = E.Keep(); d = E.block_desc(keep, blk, 0)
             if which in ('both', 'mlp'):

@@ -88,6 +88,9 @@ int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void*
   if (blk->mlp_img && mlp_fused_supported(C))
     return launch_mlp_fused(C, T, x_in, x_out, (const bf16*)blk->mlp_img, blk->fc1.b, blk->fc2.b, blk->ln2.g,
                             blk->ln2.b, s);
+  if (blk->mlp_img && mlp_stream_supported(C))
+    return launch_mlp_stream(C, T, x_in, x_out, (const bf16*)blk->mlp_img, blk->fc1.b, blk->fc2.b, blk->ln2.g,
+                             blk->ln2.b, s);
   Carver cv(ws, ws_bytes);
   bf16* xn = cv.take<bf16>((size_t)T * Cp);
   bf16* hbuf = cv.take<bf16>((size_t)T * Hp);

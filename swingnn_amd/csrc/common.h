@@ -25,19 +25,19 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
 // 1/sqrt(var + eps) of LayerNorm (v_rsq_f32, 1 ulp)
 __device__ __forceinline__ float ln_rstd(float var) { return __frsqrt_rn(var + 1e-5f); }
-// nn.GELU() exact erf form (model/swin_gnn/swin_gnn.py:10,15)
-// Exact-erf GELU (nn.GELU(), model/swin_gnn/swin_gnn.py:10,15) evaluated as  max(x,0) - |x| * q(x),
-//   q = 0.5 * erfc(|x|/sqrt2) = 0.5 * poly5(t) * exp(-x^2/2),  t = 1 / (1 + p |x|/sqrt2)
-// (Abramowitz & Stegun 7.1.26, |abs err| <= 1.5e-7 on erf): one v_rcp, one v_exp and ten FMA-class ops, no branches.
+// nn.GELU() (exact erf form, model/swin_gnn/swin_gnn.py:10,15) evaluated as x * sigmoid(x * P(x^2)) with a
+// degree-4 minimax P fitted to logit(Phi(x)):  |abs err| <= 3.5e-6 for every finite x (far below the bf16
+// rounding of the value it feeds), saturating correctly for |x| -> inf.  One v_exp, one v_rcp and eight
+// full-rate ops, no branches: the fused MLP kernels are VALU-bound on this function.
+// The coefficients carry the factor -log2(e) so that the exponential is a bare exp2.
 __device__ __forceinline__ float gelu_f(float x) {
-  const float ax = fabsf(x);
-  const float t = __frcp_rn(fmaf(0.3275911f * 0.70710678118654752440f, ax, 1.0f));
-  float p = fmaf(0.5f * 1.061405429f, t, 0.5f * -1.453152027f);
-  p = fmaf(p, t, 0.5f * 1.421413741f);
-  p = fmaf(p, t, 0.5f * -0.284496736f);
-  p = fmaf(p, t, 0.5f * 0.254829592f);
-  const float e = __builtin_amdgcn_exp2f(ax * ax * (-0.5f * 1.44269504088896340736f));
-  return fmaf(-ax, p * t * e, fmaxf(x, 0.0f));
+  const float s = x * x;
+  float q = fmaf(-3.228973355362541e-06f, s, 8.823775715427473e-05f);
+  q = fmaf(q, s, 0.00036027710302732885f);
+  q = fmaf(q, s, -0.10522669553756714f);
+  q = fmaf(q, s, -2.3020453453063965f);
+  const float e = __builtin_amdgcn_exp2f(x * q);
+  return x * __builtin_amdgcn_rcpf(1.0f + e);
 }
 
 // sum over a group of LANES consecutive lanes (LANES power of two <= 64)
@@ -147,6 +147,10 @@ int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shi
 bool mlp_fused_supported(int C);
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                      const float* g, const float* b, hipStream_t s);
+// mlp_stream.hip : the same for the wide stages (C = 384), LDS ring + skewed GELU pipeline, fragment-order image
+bool mlp_stream_supported(int C);
+int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
+                      const float* g, const float* b, hipStream_t s);
 // wattn_fused.hip : conditioning + LN1 + QKV + window attention + proj + shortcut in one pass (C = 96 / 192)
 bool wattn_fused_supported(int C, int heads, int win);
 int launch_wattn_fused(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,

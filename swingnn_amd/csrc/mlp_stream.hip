@@ -1,0 +1,279 @@
+// Fused MLP half of a Swin block for the WIDE stages (C = 384): model/swin_gnn/swin_gnn.py:275 with Mlp :19-25,
+//     x_out = x + fc2( GELU( fc1( LayerNorm2(x) ) ) )
+// Same register-resident scheme as mlp_fused.hip (tokens on lanes, the fc1 accumulators ARE the fc2 operand), but
+// built for ONE wave per SIMD with 512 registers, where nothing but the instruction order hides latency:
+//  * hidden chunks of HC features stream through an NBUF-deep LDS ring by LDS-DMA; the ring is waited for with a
+//    COUNTED s_waitcnt so NBUF-2 chunks stay in flight across the per-chunk barrier;
+//  * the hidden loop is a 3-stage software pipeline: iteration j multiplies fc1 of chunk j and fc2 of chunk j-2
+//    while the GELU of chunk j-1 runs on the VALU in the shadow of those MFMAs.  Image chunk j therefore carries the
+//    fc1 rows of hidden chunk j next to the fc2 columns of hidden chunk j-2 (zero blocks at both ends keep the body
+//    branch-free);
+//  * the body is issued as "MFMA pairs": {2 MFMAs sharing one weight fragment, the ds_read of the fragment AHEAD
+//    pairs later, one slice of the GELU, every few pairs one LDS-DMA piece}, pinned with sched_barrier because the
+//    compiler's own order (read, wait, 2 MFMAs; all VALU in one block) exposes every LDS latency;
+//  * the image is in FRAGMENT order (1 KiB per MFMA operand fragment, lane-linear), so every ds_read_b128 is
+//    conflict-free with one base register + immediate offsets, and staging is a linear copy.
+#include "common.h"
+
+namespace {
+
+struct MlpArgs {
+  const float* x;
+  float* out;
+  const bf16* img;   // weight image, see engine.py mlp_stream_image()
+  const float* b1;   // [4C]
+  const float* b2;   // [C]
+  const float* g;    // LN2 weight
+  const float* b;    // LN2 bias
+  int T;
+};
+
+typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
+typedef __attribute__((ext_vector_type(2))) float f32x2;
+typedef __attribute__((ext_vector_type(4))) unsigned u32x4;
+
+__device__ __forceinline__ unsigned pack_bf16x2(float a, float b) {
+  const f32x2 f = {a, b};
+  return __builtin_bit_cast(unsigned, __builtin_convertvector(f, bf16x2));
+}
+
+template <int N>
+__device__ __forceinline__ void wait_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+template <int C, int HC, int NBUF>
+__global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
+  constexpr int KS = C / 32;        // k-steps of fc1
+  constexpr int NT = C / 16;        // output feature tiles of fc2
+  constexpr int HT = HC / 16;       // hidden tiles per chunk (fc1 output tiles)
+  constexpr int S2 = HC / 32;       // k-steps of fc2 per chunk
+  constexpr int NCH = 4 * C / HC;   // hidden chunks; the image has NCH + 2 chunks (pipeline skew)
+  constexpr int W1_BYTES = HC * C * 2;
+  constexpr int CHUNK_BYTES = 2 * W1_BYTES;
+  constexpr int PIECES = CHUNK_BYTES / 4096;  // 1-KiB LDS-DMA pieces per wave per chunk
+  static_assert(CHUNK_BYTES % 4096 == 0 && PIECES * (NBUF - 1) < 64, "vmcnt is 6 bits");
+  static_assert(NBUF == 2 || NBUF == 3, "ring depth");
+  extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF x CHUNK_BYTES | b1 | 2 HC zeros
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int tok0 = blockIdx.x * 128 + wave * 32;
+  const unsigned smem0 = lds_addr(smem);
+
+  const char* img_lane = reinterpret_cast<const char*>(a.img) + lane * 16;
+  // LDS-DMA piece i (of PIECES per wave) of image chunk `chunk` into the ring slot at byte offset buf_off
+#define STAGE_PIECE(chunk, buf_off, i)                                                        \
+  lds_dma16(img_lane + (size_t)(chunk) * CHUNK_BYTES + ((i) * 4 + wave) * 1024,               \
+            smem0 + (buf_off) + ((i) * 4 + wave) * 1024)
+  float* sb1 = reinterpret_cast<float*>(smem + NBUF * CHUNK_BYTES);  // fc1 bias [4C] + 2 HC zeros (skew tail)
+  for (int i = tid; i < 4 * C; i += 256) sb1[i] = a.b1[i];
+  for (int i = tid; i < 2 * HC; i += 256) sb1[4 * C + i] = 0.f;
+#pragma unroll
+  for (int i = 0; i < PIECES; ++i) STAGE_PIECE(0, 0, i);
+  if (NBUF == 3) {
+#pragma unroll
+    for (int i = 0; i < PIECES; ++i) STAGE_PIECE(1, CHUNK_BYTES, i);
+  }
+
+  // ---- the wave's 32 token rows in operand layout, LayerNorm2 in registers ----
+  bf16x8 xa[2][KS];
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
+    const float* row = a.x + (size_t)tok * C;
+    float v[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p0 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg);
+      const float4 p1 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg + 4);
+      v[ks][0] = p0.x; v[ks][1] = p0.y; v[ks][2] = p0.z; v[ks][3] = p0.w;
+      v[ks][4] = p1.x; v[ks][5] = p1.y; v[ks][6] = p1.z; v[ks][7] = p1.w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) s += v[ks][j];
+    }
+    s += __shfl_xor(s, 16, 64);
+    s += __shfl_xor(s, 32, 64);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
+    q += __shfl_xor(q, 16, 64);
+    q += __shfl_xor(q, 32, 64);
+    const float rstd = ln_rstd(q * (1.0f / C));
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 g0 = *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg);
+      const float4 g1 = *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg + 4);
+      const float4 b0 = *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg);
+      const float4 b1 = *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg + 4);
+      const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+      const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+      bf16x8 f;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) f[j] = (bf16)((v[ks][j] - mean) * rstd * gg[j] + bb[j]);
+      xa[mt][ks] = f;
+    }
+  }
+
+  f32x4 acc[NT][2];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  constexpr int NV = HT * 2 * 4;           // GELU evaluations per lane per chunk
+  constexpr int PAIRS = KS * HT + S2 * NT;  // weight fragments == MFMA pairs per iteration
+  constexpr int NVEC = HT * 2;              // ... as f32x4 accumulator vectors
+  constexpr int NSL = 11 * NVEC;            // GELU slices (eleven levels per vector)
+  constexpr int AHEAD = 6;                  // fragment reads in flight ahead of their MFMAs
+  constexpr int DMA_EVERY = PAIRS / PIECES;
+  static_assert(PAIRS % PIECES == 0 && AHEAD < PAIRS && NSL <= PAIRS, "schedule shape");
+  f32x4 hcur[HT][2];   // fc1 output (+bias) of chunk j-1
+  u32x4 hb[2][S2];     // GELU output of chunk j-2 as fc2 operand (packed bf16)
+#pragma unroll
+  for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) hcur[ht][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+    for (int s2 = 0; s2 < S2; ++s2) hb[mt][s2] = (u32x4){0u, 0u, 0u, 0u};
+
+  __syncthreads();  // sb1 visible (the LDS-DMA above is inline asm: no vmcnt(0) is emitted for it here)
+  unsigned bo = 0;  // byte offset of the ring slot holding chunk j
+#pragma nounroll
+  for (int j = 0; j < NCH + 2; ++j) {
+    // chunk j has landed in every wave's view; NBUF-2 younger chunks may stay in flight
+    // (the refill below runs in every iteration -- past the end it re-copies the last chunk into a dead slot --
+    // so the count is the same every time)
+    wait_vmcnt<(NBUF - 2) * PIECES>();
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");  // no LDS read of this iteration may move above the barrier
+    // every wave is now past its reads of the slot used one iteration ago: it is refilled piece by piece below
+    const unsigned prev = (bo == 0) ? (NBUF - 1) * CHUNK_BYTES : bo - CHUNK_BYTES;
+    const int next_chunk = min(j + NBUF - 1, NCH + 1);
+    const char* cb = smem + bo + lane * 16;
+    const float* bj = sb1 + j * HC + 4 * lg;
+
+    f32x4 hn[HT][2];       // fc1 accumulators of chunk j, initial value = bias
+    u32x4 hbn[2][S2];      // GELU output of chunk j-1 (next iteration's fc2 operand)
+    float gs[NV], gq[NV];  // GELU pipeline state
+    bf16x8 fr[AHEAD + 1];  // fragment ring
+#define FRAG_PTR(P) (cb + ((P) < KS * HT ? (P) * 1024 : W1_BYTES + ((P) - KS * HT) * 1024))
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht) {
+      const f32x4 bb = *reinterpret_cast<const f32x4*>(bj + ht * 16);
+      hn[ht][0] = bb;
+      hn[ht][1] = bb;
+    }
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p) fr[p] = *reinterpret_cast<const bf16x8*>(FRAG_PTR(p));
+    __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+    for (int p = 0; p < PAIRS; ++p) {
+      // -- two MFMAs on fragment p: fc1 fragment (k-step, hidden tile) or fc2 fragment (k-step, out tile)
+      const bf16x8 w = fr[p % (AHEAD + 1)];
+      if (p < KS * HT) {
+        const int ks = p / HT, ht = p % HT;
+        hn[ht][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xa[0][ks], hn[ht][0], 0, 0, 0);
+        hn[ht][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xa[1][ks], hn[ht][1], 0, 0, 0);
+      } else {
+        const int q = p - KS * HT, s2 = q / NT, nt = q % NT;
+        acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, __builtin_bit_cast(bf16x8, hb[0][s2]), acc[nt][0], 0, 0, 0);
+        acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, __builtin_bit_cast(bf16x8, hb[1][s2]), acc[nt][1], 0, 0, 0);
+      }
+      // -- fragment read AHEAD pairs ahead
+      if (p + AHEAD < PAIRS) fr[(p + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(FRAG_PTR(p + AHEAD));
+      // -- one LDS-DMA piece of chunk j+NBUF-1 every DMA_EVERY pairs
+      if (p % DMA_EVERY == 1) STAGE_PIECE(next_chunk, prev, p / DMA_EVERY);
+      // -- GELU of chunk j-1 (gelu_f of common.h, spelled out): vector t = ht*2+mt (4 independent values) advances
+      //    one LEVEL per slice, the vectors take turns, so dependent VALU ops are several pairs apart
+      if (p < NSL) {  // one slice per pair (NSL <= PAIRS)
+        const int sl = p;
+        const int t = sl % NVEC, level = sl / NVEC, ht = t >> 1, mt = t & 1;
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int v = t * 4 + r;
+          const float x = hcur[ht][mt][r];
+          if (level == 0) gs[v] = x * x;
+          else if (level == 1) gq[v] = fmaf(-3.228973355362541e-06f, gs[v], 8.823775715427473e-05f);
+          else if (level == 2) gq[v] = fmaf(gq[v], gs[v], 0.00036027710302732885f);
+          else if (level == 3) gq[v] = fmaf(gq[v], gs[v], -0.10522669553756714f);
+          else if (level == 4) gq[v] = fmaf(gq[v], gs[v], -2.3020453453063965f);
+          else if (level == 5) gq[v] = x * gq[v];
+          else if (level == 6) gq[v] = __builtin_amdgcn_exp2f(gq[v]);
+          else if (level == 7) gq[v] = 1.0f + gq[v];
+          else if (level == 8) gq[v] = __builtin_amdgcn_rcpf(gq[v]);
+          else if (level == 9) gq[v] = x * gq[v];
+          else if (r & 1) hbn[mt][ht >> 1][(ht & 1) * 2 + (r >> 1)] = pack_bf16x2(gq[v - 1], gq[v]);
+        }
+      }
+      __builtin_amdgcn_sched_barrier(0);
+    }
+#undef FRAG_PTR
+#pragma unroll
+    for (int ht = 0; ht < HT; ++ht)
+#pragma unroll
+      for (int mt = 0; mt < 2; ++mt) hcur[ht][mt] = hn[ht][mt];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt)
+#pragma unroll
+      for (int s2 = 0; s2 < S2; ++s2) hb[mt][s2] = hbn[mt][s2];
+    bo = (bo == (NBUF - 1) * CHUNK_BYTES) ? 0u : bo + CHUNK_BYTES;
+  }
+#undef STAGE_PIECE
+  wait_vmcnt<0>();  // the trailing refills must have landed before the workgroup's LDS is released
+
+  // ---- epilogue: + b2 + residual (re-read, L2/MALL-warm), fp32 store.  fc2 image rows are rho-ordered: accumulator
+  // row 4*lg+r of tile nt = 2*ks+hh is channel 32*ks + 8*lg + 4*hh + r, so a lane stores 32 contiguous bytes.
+#pragma unroll
+  for (int mt = 0; mt < 2; ++mt) {
+    const int tok = tok0 + mt * 16 + l15;
+    if (tok >= a.T) continue;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      const int c = 32 * (nt >> 1) + 8 * lg + 4 * (nt & 1);
+      const float4 bb = *reinterpret_cast<const float4*>(a.b2 + c);
+      const float4 r4 = *reinterpret_cast<const float4*>(a.x + (size_t)tok * C + c);
+      float4 o;
+      o.x = acc[nt][mt][0] + bb.x + r4.x;
+      o.y = acc[nt][mt][1] + bb.y + r4.y;
+      o.z = acc[nt][mt][2] + bb.z + r4.z;
+      o.w = acc[nt][mt][3] + bb.w + r4.w;
+      *reinterpret_cast<float4*>(a.out + (size_t)tok * C + c) = o;
+    }
+  }
+}
+
+template <int C, int HC, int NBUF>
+int launch_one(const MlpArgs& a, hipStream_t s) {
+  constexpr size_t lds = (size_t)NBUF * (4 * HC * C) + (size_t)(4 * C + HC) * sizeof(float);
+  static bool attr_set = false;  // dynamic LDS above 64 KiB needs an explicit opt-in
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_stream<C, HC, NBUF>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_mlp_stream<C, HC, NBUF>), dim3(cdiv(a.T, 128)), dim3(256), lds, s, a);
+  return 0;
+}
+
+}  // namespace
+
+bool mlp_stream_supported(int C) { return C == 384; }
+
+int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
+                      const float* g, const float* b, hipStream_t s) {
+  if (!mlp_stream_supported(C)) return SWG_E_UNSUPPORTED;
+  if (T <= 0) return 0;
+  MlpArgs a = {x, out, img, b1, b2, g, b, T};
+  SwgProfScope ps(KID_FUSED_MLP, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
+  int rc = launch_one<384, 32, 3>(a, s);
+  if (rc) return rc;
+  SWG_LAUNCH_CHECK();
+  return 0;
+}

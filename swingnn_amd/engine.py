@@ -113,6 +113,29 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     return torch.cat([a, b], dim=1).to(torch.bfloat16).contiguous()
 
 
+STREAM_MLP_HC = {384: 32}  # hidden chunk width of csrc/mlp_stream.hip per channel count
+
+
+def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int) -> torch.Tensor:
+    """Weight image of csrc/mlp_stream.hip, in MFMA fragment order (1 KiB = 64 lanes x 8 bf16 per fragment, lane
+    16*lg + i holds row i, k-slots 8*lg .. 8*lg+7).  Image chunk j (j = 0 .. 4C/hc + 1) is
+      [fc1 rows of hidden chunk j   as fragments (k-step, hidden tile)]
+      [fc2 cols of hidden chunk j-2 as fragments (k-step, rho-ordered out tile), k-slot order pi]
+    with zero blocks where the hidden chunk does not exist (the kernel's loop is a 3-stage pipeline)."""
+    w1, w2 = w1.detach().float(), w2.detach().float()
+    H, Cdim = w1.shape
+    nch, ks, ht, s2, nt = H // hc, Cdim // 32, hc // 16, hc // 32, Cdim // 16
+    dev = w1.device
+    # fc1 part: [chunk, ks, ht, lg, i, e] <- w1[chunk*hc + ht*16 + i, ks*32 + lg*8 + e]
+    a = w1.reshape(nch, ht, 16, ks, 4, 8).permute(0, 3, 1, 4, 2, 5).reshape(nch, -1)
+    # fc2 part: [chunk, s2, nt, lg, i, e] <- w2[rho(nt*16 + i), chunk*hc + s2*32 + pi(lg, e)]
+    b = w2[_rho(Cdim, dev)].reshape(nt, 16, nch, s2, 32)[..., _pi(dev)].reshape(nt, 16, nch, s2, 4, 8)
+    b = b.permute(2, 3, 0, 4, 1, 5).reshape(nch, -1)
+    z = torch.zeros(2, a.shape[1], device=dev)
+    img = torch.cat([torch.cat([a, z], 0), torch.cat([z, b], 0)], dim=1)  # [nch + 2, W1 part | W2 part]
+    return img.to(torch.bfloat16).contiguous()
+
+
 FUSED_ATTN_DIMS = (96, 192)
 FUSED_ATTN_WINDOWS = (6,)
 USE_FUSED_ATTN = True
@@ -160,6 +183,8 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
         aimg = _ptr(keep(wattn_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads)))
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
         img = _ptr(keep(mlp_image(blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
+    elif USE_FUSED_MLP and blk.dim in STREAM_MLP_HC:
+        img = _ptr(keep(mlp_stream_image(blk.mlp.fc1.weight, blk.mlp.fc2.weight, STREAM_MLP_HC[blk.dim])))
     return L.SwgBlock(blk.dim, blk.input_resolution[0], blk.window_size, blk.shift_size, blk.num_heads, cond_off,
                       keep.ln(blk.norm1), keep.ln(blk.norm2),
                       keep.lin(blk.attn.qkv.weight, blk.attn.qkv.bias), keep.lin(blk.attn.proj.weight, blk.attn.proj.bias),

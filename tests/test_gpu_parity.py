@@ -74,6 +74,44 @@ def test_swin_block(S, golden, name):
     rel_close(out, ref)
 
 
+# block geometries beyond the golden set (oracle only): the wide-stage kernels at a token count that is not a
+# multiple of any tile (432 = 3 x 128 + 48), shifted windows
+EXTRA_BLOCK_CASES = {
+    "r12_w6_s3_c384": dict(C=384, res=12, heads=12, window=6, shift=3, B=3, seed=71),
+    "r12_w6_s0_c384": dict(C=384, res=12, heads=12, window=6, shift=0, B=1, seed=72),
+}
+
+
+@pytest.mark.parametrize("name", list(EXTRA_BLOCK_CASES))
+def test_swin_block_vs_oracle(S, name):
+    c = EXTRA_BLOCK_CASES[name]
+    w, s = O.eff_window(c["res"], c["window"], c["shift"])
+    full = H.block_state(c["C"], c["heads"], w, c["seed"])
+    blk = load(S.SwinTransformerBlock(c["C"], 512, (c["res"],) * 2, c["heads"], c["window"], c["shift"]),
+               strip(full, "blk."))
+    x = filler.uniform("x", (c["B"], c["res"] ** 2, c["C"]), c["seed"])
+    emb = filler.uniform("emb", (c["B"], 512), c["seed"])
+    out = blk(x.to(DEV), emb.to(DEV))
+    ref = O.swin_block(x, emb, full, "blk", c["res"], c["heads"], c["window"], c["shift"])
+    rel_close(out, ref)
+    # MLP half alone, tight: zero attention projection -> x + mlp(ln2(x)) against fp32 torch
+    import torch.nn.functional as F
+    xd = x.to(DEV).reshape(-1, c["C"])
+    g = {k: v.to(DEV) for k, v in strip(full, "blk.").items() if k.startswith(("norm2", "mlp"))}
+    xn = F.layer_norm(xd, (c["C"],), g["norm2.weight"], g["norm2.bias"])
+    want = xd + F.linear(F.gelu(F.linear(xn, g["mlp.fc1.weight"], g["mlp.fc1.bias"])), g["mlp.fc2.weight"],
+                         g["mlp.fc2.bias"])
+    import ctypes as C
+    from swingnn_amd import _lib as L, engine as E
+    keep = E.Keep()
+    desc = E.block_desc(keep, blk, 0)
+    got = torch.empty_like(xd)
+    ws = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)
+    L.check(L.lib.swg_ln_mlp_fwd(C.byref(desc), c["B"], xd.data_ptr(), got.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 E.stream_ptr()), "swg_ln_mlp_fwd")
+    rel_close(got, want.cpu(), max_rel=2e-2, mean_rel=2e-3)
+
+
 def test_block_attention_half_only(S):
     """swg_wattn_fwd alone (no MLP) against the oracle's attention half, shifted 6x6 windows."""
     import ctypes as C
