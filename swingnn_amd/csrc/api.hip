@@ -63,6 +63,19 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
   const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C), ldq = ldq_of(C);
   if (blk->attn_img && wattn_fused_supported(C, blk->heads, blk->win))
     return launch_wattn_fused(blk, B, x_in, cond, cond_stride, x_out, s);
+  if (blk->attn_img && wattn_stream_supported(C, blk->heads, blk->win)) {
+    // two kernels: attention core on LN1'd rows -> o (bf16, head-dim slots in accumulator order), then the
+    // projection GEMM on the slot-permuted Wproj (stored behind the slab image) with the shortcut recomputed
+    Carver cv(ws, ws_bytes);
+    bf16* o = cv.take<bf16>((size_t)T * Cp);
+    if (!cv.ok) return SWG_E_WORKSPACE;
+    if ((r = launch_wattn_stream(blk, B, x_in, cond, cond_stride, o, Cp, s))) return r;
+    const bf16* wp = (const bf16*)blk->attn_img + (size_t)3 * C * C;
+    GemmEpi e2 = {};
+    e2.bias = blk->proj.b; e2.residual = x_in; e2.ldr = C; e2.out_f32 = x_out; e2.ldo = C;
+    e2.cond = cond; e2.cond_stride = cond_stride; e2.cond_off = blk->cond_off; e2.cond_L = L;
+    return launch_gemm(o, Cp, wp, T, C, Cp, e2, s);
+  }
   Carver cv(ws, ws_bytes);
   float* x1 = cv.take<float>((size_t)T * C);
   bf16* xn = cv.take<bf16>((size_t)T * Cp);

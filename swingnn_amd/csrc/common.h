@@ -48,6 +48,22 @@ __device__ __forceinline__ float group_sum(float v) {
   return v;
 }
 
+// Reductions over the four 16-lane rows of a wavefront (lanes l, l^16, l^32, l^48) with the gfx950 row-swap
+// instructions: v_permlane{16,32}_swap exchange register rows in the VALU, no LDS round trip (ds_bpermute costs an
+// LDS latency per step, which one wave per SIMD cannot hide).  Every lane ends with the full result.
+__device__ __forceinline__ float rows_sum(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+__device__ __forceinline__ float rows_max(float v) {
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __builtin_fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  return __builtin_fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+
 __device__ __forceinline__ uint2 pack_bf16x4(float a, float b, float c, float d) {
   bf16x4 v = {(bf16)a, (bf16)b, (bf16)c, (bf16)d};
   return *reinterpret_cast<uint2*>(&v);
@@ -133,6 +149,10 @@ struct GemmEpi {
   const float* bias;      // [N] or null
   const float* residual;  // fp32 [M, ldr] or null
   int ldr;
+  // optional conditioning of the residual: r <- silu(shift + r (1 + scale)) with scale = cond[m / cond_L][cond_off + n],
+  // shift = cond[m / cond_L][cond_off + N + n]  (the block shortcut of swin_gnn.py:238-242, recomputed in the epilogue)
+  const float* cond;
+  int cond_stride, cond_off, cond_L;
   int act;                // 0 none, 1 gelu
   float* out_f32;         // fp32 [M, ldo] or null
   bf16* out_bf16;         // bf16 [M, ldo] or null; columns [N, n_store) are written as zero
@@ -143,6 +163,15 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
 // wattn.hip : window attention core on a qkv buffer
 int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shift, int heads, int C, const float* rpb,
                       bf16* o, int ldo, hipStream_t s);
+// wattn_stream.hip : conditioning + LN1 + QKV + window attention for the wide stages (C = 384) -> o (bf16, pi slots)
+bool wattn_stream_supported(int C, int heads, int win);
+int launch_wattn_stream(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, bf16* o,
+                        int ldo, hipStream_t s);
+// embed_mfma.hip : MFMA forms of patch embedding and final LN + read-out for p = 4, C0 = 96
+bool embed_mfma_supported(const swg_net* net);
+int launch_patch_embed_mfma(const swg_net* net, int B, const float* x, const float* sc, const float* c_in,
+                            int c_in_stride, const float* cond, int cond_stride, float* tok, hipStream_t s);
+int launch_final_readout_mfma(const swg_net* net, int B, const float* tok, float* F, hipStream_t s);
 // mlp_fused.hip : x_out = x + fc2(GELU(fc1(LN2(x)))) in one pass (C = 96 / 192)
 bool mlp_fused_supported(int C);
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,

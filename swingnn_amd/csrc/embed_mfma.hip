@@ -1,0 +1,229 @@
+// MFMA forms of the two 4x4-patch kernels at the ends of the network (p = 4, C0 = 96 -- the grid / DD geometry):
+//   * PatchEmbed (swin_gnn.py:562-577 + self-cond concat :769-771 + c_in of precond.py:47): a [tokens x 32 taps] x
+//     [32 x C] product is exactly ONE 16x16x32 k-step per 16 tokens x 16 channels;
+//   * final LayerNorm + collapsed read-out (:748, :697-701): [tokens x C] x [C x 16 pixels].
+// Both are HBM-bound (the fp32 token stream is 4*C bytes per token); the scalar-FMA versions in rowops.hip were
+// VALU/LDS-bound at a quarter of the HBM rate.  The matrix core works on bf16, so every fp32 operand is split into
+// hi + lo bf16 parts and the product is taken as hi*hi + lo*hi + hi*lo (relative error ~2^-16: fp32-grade for this
+// path, whose other layers round activations to bf16 once).
+// Persistent waves: weights / LN constants are converted to fragments once per wave, then the wave walks over
+// 16-token tiles.  Token on the lane (l & 15), 8 consecutive taps / channels per lane group (l >> 4).
+#include "common.h"
+
+namespace {
+
+struct EmbedMfmaArgs {
+  const float* x; const float* sc; const float* c_in; int c_in_stride;
+  const float* cond; int cond_stride, cond_off;
+  const float* w; const float* bias; const float* g; const float* b;
+  float* tok;
+  int B, N, in_ch, self_cond;
+};
+
+__device__ __forceinline__ void split_bf16(const float (&f)[8], bf16x8& hi, bf16x8& lo) {
+#pragma unroll
+  for (int e = 0; e < 8; ++e) {
+    const bf16 h = (bf16)f[e];
+    hi[e] = h;
+    lo[e] = (bf16)(f[e] - (float)h);
+  }
+}
+
+// channel held by accumulator row i of output tile nt (the rho order of engine.py): a lane's rows 4*lg..4*lg+3 of
+// tiles 2k, 2k+1 are 8 consecutive channels -> 32-byte stores per lane, full 128-byte lines per token
+__device__ __forceinline__ int rho_chan(int nt, int i) { return 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3); }
+
+template <int C>
+__global__ __launch_bounds__(256) void k_patch_embed_mfma(EmbedMfmaArgs a) {
+  constexpr int NT = C / 16;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int kin = a.in_ch * 16;
+
+  bf16x8 wh[NT], wl[NT];
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) {
+    const int c = rho_chan(nt, l15);
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int k = 8 * lg + e;
+      f[e] = (k < kin) ? a.w[c * kin + k] : 0.f;
+    }
+    split_bf16(f, wh[nt], wl[nt]);
+  }
+  f32x4 cb[NT];  // conv bias of this lane's channels (LN weight / bias are re-read per tile: L1 hits, 48 VGPRs less)
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt) cb[nt] = *reinterpret_cast<const f32x4*>(a.bias + rho_chan(nt, 4 * lg));
+
+  const int hp = a.N >> 2, L = hp * hp, rows = a.B * L;
+  const int ntiles = (rows + 15) >> 4;
+  // this lane's taps: channel ci = lg >> 1 of cat([self_cond, x]), patch rows ii0, ii0 + 1
+  const int ci = lg >> 1, ii0 = (lg & 1) * 2;
+  const bool has = ci < a.in_ch;
+  const bool is_x = (!a.self_cond) || ci == a.in_ch - 1;
+  const float* src = is_x ? a.x : a.sc;
+
+  const bool live = has && src != nullptr;
+  const int stride_t = gridDim.x * 4;
+  // the taps of the NEXT tile are fetched while the current one is computed (one tile in flight per wave)
+  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
+  float nsc = 1.0f;
+  auto fetch = [&](int tile) {
+    if (!live || tile >= ntiles) return;
+    const int row = min(tile * 16 + l15, rows - 1);
+    const int bi = row / L, rem = row - bi * L;
+    const int Y = rem / hp, X = rem - Y * hp;
+    const float* p0 = src + ((size_t)bi * a.N + (Y * 4 + ii0)) * a.N + X * 4;
+    n0 = *reinterpret_cast<const float4*>(p0);
+    n1 = *reinterpret_cast<const float4*>(p0 + a.N);
+    nsc = (is_x && a.c_in) ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f;
+  };
+  fetch(blockIdx.x * 4 + wave);
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += stride_t) {
+    const int row = min(tile * 16 + l15, rows - 1);
+    const int bi = row / L;
+    const float4 r0 = n0, r1 = n1;
+    const float sc = nsc;
+    fetch(tile + stride_t);
+    const float f[8] = {sc * r0.x, sc * r0.y, sc * r0.z, sc * r0.w, sc * r1.x, sc * r1.y, sc * r1.z, sc * r1.w};
+    bf16x8 xh, xl;
+    split_bf16(f, xh, xl);
+    f32x4 acc[NT];
+    float s = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xh, cb[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xl, acc[nt], 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], xh, acc[nt], 0, 0, 0);
+    }
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) s += (acc[nt][0] + acc[nt][1]) + (acc[nt][2] + acc[nt][3]);
+    s = rows_sum(s);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) { const float d = acc[nt][r] - mean; q += d * d; }
+    q = rows_sum(q);
+    const float rstd = ln_rstd(q * (1.0f / C));
+    if (tile * 16 + l15 < rows) {
+      const float* crow = a.cond + (size_t)bi * a.cond_stride + a.cond_off;
+      float* orow = a.tok + (size_t)row * C;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = rho_chan(nt, 4 * lg);
+        const f32x4 sc = *reinterpret_cast<const f32x4*>(crow + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(crow + C + c);
+        const f32x4 cg = *reinterpret_cast<const f32x4*>(a.g + c);
+        const f32x4 cbeta = *reinterpret_cast<const f32x4*>(a.b + c);
+        f32x4 y;
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          y[r] = silu_f(sh[r] + ((acc[nt][r] - mean) * rstd * cg[r] + cbeta[r]) * (sc[r] + 1.f));
+        *reinterpret_cast<f32x4*>(orow + c) = y;
+      }
+    }
+  }
+}
+
+struct ReadoutMfmaArgs {
+  const float* tok; const float* g; const float* b; const float* w; float bias; float* F;
+  int B, N;
+};
+
+template <int C>
+__global__ __launch_bounds__(256) void k_final_readout_mfma(ReadoutMfmaArgs a) {
+  constexpr int KS = C / 32;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  bf16x8 wh[KS], wl[KS];  // A operand: row = output pixel o = l15 (4x4 patch, o = 4*i + j), k = channel
+  float cg[KS][8], cbeta[KS][8];
+#pragma unroll
+  for (int ks = 0; ks < KS; ++ks) {
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) {
+      const int c = 32 * ks + 8 * lg + e;
+      f[e] = a.w[c * 16 + l15];
+      cg[ks][e] = a.g[c];
+      cbeta[ks][e] = a.b[c];
+    }
+    split_bf16(f, wh[ks], wl[ks]);
+  }
+  const int hp = a.N >> 2, L = hp * hp, rows = a.B * L;
+  const int ntiles = (rows + 15) >> 4;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row = min(tile * 16 + l15, rows - 1);
+    const float* xr = a.tok + (size_t)row * C + 8 * lg;
+    float v[KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      const float4 p0 = *reinterpret_cast<const float4*>(xr + 32 * ks);
+      const float4 p1 = *reinterpret_cast<const float4*>(xr + 32 * ks + 4);
+      v[ks][0] = p0.x; v[ks][1] = p0.y; v[ks][2] = p0.z; v[ks][3] = p0.w;
+      v[ks][4] = p1.x; v[ks][5] = p1.y; v[ks][6] = p1.z; v[ks][7] = p1.w;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) s += v[ks][e];
+    }
+    s = rows_sum(s);
+    const float mean = s * (1.0f / C);
+    float q = 0.f;
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { const float d = v[ks][e] - mean; q += d * d; }
+    q = rows_sum(q);
+    const float rstd = ln_rstd(q * (1.0f / C));
+    f32x4 acc = {a.bias, a.bias, a.bias, a.bias};
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks) {
+      float y[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) y[e] = (v[ks][e] - mean) * rstd * cg[ks][e] + cbeta[ks][e];
+      bf16x8 yh, yl;
+      split_bf16(y, yh, yl);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], yh, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[ks], yl, acc, 0, 0, 0);
+      acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[ks], yh, acc, 0, 0, 0);
+    }
+    if (tile * 16 + l15 < rows) {
+      // accumulator rows 4*lg .. 4*lg+3 of this token = pixels (i = lg, j = 0..3) of its patch: one float4 store
+      const int bi = row / L, rem = row - bi * L;
+      const int Y = rem / hp, X = rem - Y * hp;
+      *reinterpret_cast<f32x4*>(a.F + ((size_t)bi * a.N + (Y * 4 + lg)) * a.N + X * 4) = acc;
+    }
+  }
+}
+
+int persistent_grid(int ntiles) { return max(1, min(cdiv(ntiles, 4), 256 * 8)); }
+
+}  // namespace
+
+bool embed_mfma_supported(const swg_net* net) {
+  return net->p == 4 && net->C0 == 96 && net->N % 4 == 0 && net->in_ch >= 1 && net->in_ch <= 2;
+}
+
+int launch_patch_embed_mfma(const swg_net* net, int B, const float* x, const float* sc, const float* c_in,
+                            int c_in_stride, const float* cond, int cond_stride, float* tok, hipStream_t s) {
+  EmbedMfmaArgs a = {x, sc, c_in, c_in_stride, cond, cond_stride, net->pe_cond_off, net->pe_w, net->pe_b,
+                     net->pe_ln.g, net->pe_ln.b, tok, B, net->N, net->in_ch, net->self_cond};
+  const int hp = net->N / 4, rows = B * hp * hp;
+  SwgProfScope ps(KID_PATCH_EMBED, 2.0 * rows * 96.0 * 16 * net->in_ch,
+                  4.0 * B * (double)net->N * net->N * (sc ? 2 : 1) + 4.0 * rows * 96.0, s);
+  hipLaunchKernelGGL((k_patch_embed_mfma<96>), dim3(persistent_grid(cdiv(rows, 16))), dim3(256), 0, s, a);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_final_readout_mfma(const swg_net* net, int B, const float* tok, float* F, hipStream_t s) {
+  ReadoutMfmaArgs a = {tok, net->norm.g, net->norm.b, net->ro_w, net->ro_b, F, B, net->N};
+  const int hp = net->N / 4, rows = B * hp * hp;
+  SwgProfScope ps(KID_READOUT, 2.0 * rows * 96.0 * 16, 4.0 * rows * 96.0 + 4.0 * B * (double)net->N * net->N, s);
+  hipLaunchKernelGGL((k_final_readout_mfma<96>), dim3(persistent_grid(cdiv(rows, 16))), dim3(256), 0, s, a);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}

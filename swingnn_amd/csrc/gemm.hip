@@ -12,8 +12,6 @@
 //    of tile k+1 are in flight while tile k is multiplied (one barrier per K tile).
 //  * blockIdx is remapped so that consecutive logical tiles (which share the activation row panel) land on
 //    the same XCD and hit its L2.
-#include <stdlib.h>
-
 #include "common.h"
 
 namespace {
@@ -130,6 +128,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
   for (int mt = 0; mt < 4; ++mt) {
     const int m = m0 + wm * 64 + mt * 16 + l15;
     if (m >= M) continue;
+    const float* crow = e.cond ? e.cond + (size_t)(m / e.cond_L) * e.cond_stride + e.cond_off : nullptr;
 #pragma unroll
     for (int nt = 0; nt < 4; ++nt) {
       const int n = n0 + wn * 64 + nt * 16 + 4 * lg;
@@ -143,7 +142,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
         }
         if (e.act == 1) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
         if (e.residual) {
-          const float4 rr = *reinterpret_cast<const float4*>(e.residual + (size_t)m * e.ldr + n);
+          float4 rr = *reinterpret_cast<const float4*>(e.residual + (size_t)m * e.ldr + n);
+          if (crow) {
+            const float4 sc = *reinterpret_cast<const float4*>(crow + n);
+            const float4 sh = *reinterpret_cast<const float4*>(crow + N + n);
+            rr.x = silu_f(sh.x + rr.x * (sc.x + 1.f)); rr.y = silu_f(sh.y + rr.y * (sc.y + 1.f));
+            rr.z = silu_f(sh.z + rr.z * (sc.z + 1.f)); rr.w = silu_f(sh.w + rr.w * (sc.w + 1.f));
+          }
           v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
         }
       }
@@ -170,8 +175,7 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   const double osz = ee.out_f32 ? 4.0 : 2.0;
   SwgProfScope ps(KID_GEMM, 2.0 * M * (double)N * Kp,
                   2.0 * M * Kp + 2.0 * N * (double)Kp + osz * M * (double)N + (ee.residual ? 4.0 * M * (double)N : 0.0), s);
-  static const bool force32 = getenv("SWG_GEMM_BK32") != nullptr;
-  if (Kp % 64 == 0 && !force32)
+  if (Kp % 64 == 0)
     hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
   else
     hipLaunchKernelGGL(k_gemm_nt<32>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);

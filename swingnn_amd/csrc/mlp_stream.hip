@@ -93,16 +93,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[ks][j];
     }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = rows_sum(s);
     const float mean = s * (1.0f / C);
     float q = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
+    q = rows_sum(q);
     const float rstd = ln_rstd(q * (1.0f / C));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {

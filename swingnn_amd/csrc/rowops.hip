@@ -387,6 +387,8 @@ __global__ __launch_bounds__(256) void k_patch_embed(EmbedArgs a) {
 
 int launch_patch_embed(const swg_net* net, int B, const float* x, const float* sc, const float* c_in, int c_in_stride,
                        const float* cond, int cond_stride, float* tok, hipStream_t s) {
+  if (embed_mfma_supported(net))
+    return launch_patch_embed_mfma(net, B, x, sc, c_in, c_in_stride, cond, cond_stride, tok, s);
   const int kin = net->in_ch * net->p * net->p;
   if (kin > 32 || net->N % net->p || net->C0 % 4) return SWG_E_UNSUPPORTED;
   if (net->self_cond ? net->in_ch != 2 : net->in_ch != 1) return SWG_E_UNSUPPORTED;
@@ -485,6 +487,7 @@ __global__ __launch_bounds__(256) void k_final_readout(ReadoutArgs a) {
 }
 
 int launch_final_readout(const swg_net* net, int B, const float* tok, float* F, hipStream_t s) {
+  if (embed_mfma_supported(net)) return launch_final_readout_mfma(net, B, tok, F, s);
   if (net->p * net->p > 16) return SWG_E_UNSUPPORTED;
   ReadoutArgs a = {tok, net->norm.g, net->norm.b, net->ro_w, net->ro_b, F, B, net->N, net->p, net->C0};
   const int hp = net->N / net->p;

@@ -62,6 +62,8 @@ __global__ __launch_bounds__(256, LB) void k_wattn_fused(FusedAttnArgs a) {
   const int b = wi_g / nW, wi = wi_g - b * nW;
   const int wy = wi / nwx, wx = wi - wy * nwx;
   const int Ltok = a.res * a.res;
+  // region ids differ inside a window only in the last window row / column of a shifted block
+  const bool need_mask = __builtin_amdgcn_readfirstlane((int)(a.shift > 0 && (wy == nwx - 1 || wx == nwx - 1))) != 0;
   const int w2 = 2 * a.win - 1;
 
   auto stage = [&](int h, int buf) {
@@ -153,16 +155,14 @@ __global__ __launch_bounds__(256, LB) void k_wattn_fused(FusedAttnArgs a) {
         s += v;
       }
     }
-    s += __shfl_xor(s, 16, 64);
-    s += __shfl_xor(s, 32, 64);
+    s = rows_sum(s);
     const float mean = s * (1.0f / C);
     float q = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
       for (int j = 0; j < 8; ++j) { const float d = x1[xi][ks][j] - mean; q += d * d; }
-    q += __shfl_xor(q, 16, 64);
-    q += __shfl_xor(q, 32, 64);
+    q = rows_sum(q);
     const float rstd = ln_rstd(q * (1.0f / C));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
@@ -311,7 +311,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_fused(FusedAttnArgs a) {
           if (kt == NTM - 1) sv += kpad[r];
           p[kt][qt][r] = sv;
         }
-    if (a.shift > 0) {  // wave-uniform: only the shifted blocks pay for the region mask (:207-226)
+    if (need_mask) {  // wave-uniform: only the border windows of shifted blocks pay for the region mask (:207-226)
 #pragma unroll
       for (int kt = 0; kt < NTM; ++kt)
 #pragma unroll
@@ -328,8 +328,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_fused(FusedAttnArgs a) {
       for (int kt = 0; kt < NTM; ++kt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) mx = fmaxf(mx, p[kt][qt][r]);
-      mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-      mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+      mx = rows_max(mx);
       float sum = 0.f;
 #pragma unroll
       for (int kt = 0; kt < NTM; ++kt)
@@ -339,8 +338,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_fused(FusedAttnArgs a) {
           p[kt][qt][r] = e;
           sum += e;
         }
-      sum += __shfl_xor(sum, 16, 64);
-      sum += __shfl_xor(sum, 32, 64);
+      sum = rows_sum(sum);
       inv_sum[qt] = __frcp_rn(sum);
     }
 
