@@ -63,13 +63,22 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
   const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C), ldq = ldq_of(C);
   if (blk->attn_img && wattn_fused_supported(C, blk->heads, blk->win))
     return launch_wattn_fused(blk, B, x_in, cond, cond_stride, x_out, s);
-  if (blk->attn_img && wattn_stream_supported(C, blk->heads, blk->win)) {
-    // two kernels: attention core on LN1'd rows -> o (bf16, head-dim slots in accumulator order), then the
-    // projection GEMM on the slot-permuted Wproj (stored behind the slab image) with the shortcut recomputed
+  if (blk->attn_img && wattn_ring_supported(C, blk->heads, blk->win, blk->res)) {
     Carver cv(ws, ws_bytes);
+    bf16* xn = nullptr;
+    if (wattn_ring_wants_xn(C)) {  // xn = LN1(silu(shift + x(1+scale))) in bf16 (:238-244)
+      xn = cv.take<bf16>((size_t)T * Cp);
+      if (!cv.ok) return SWG_E_WORKSPACE;
+      if ((r = launch_cond_ln(x_in, T, C, L, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, nullptr, xn, Cp, s)))
+        return r;
+    }
+    if (wattn_ring_fuses_proj(C))
+      return launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, x_out, nullptr, 0, s);
+    // two kernels: attention core -> o (bf16, head-dim slots in accumulator order), then the projection GEMM on the
+    // slot-permuted Wproj (stored behind the fragment stream) with the shortcut recomputed in its epilogue
     bf16* o = cv.take<bf16>((size_t)T * Cp);
     if (!cv.ok) return SWG_E_WORKSPACE;
-    if ((r = launch_wattn_stream(blk, B, x_in, cond, cond_stride, o, Cp, s))) return r;
+    if ((r = launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, nullptr, o, Cp, s))) return r;
     const bf16* wp = (const bf16*)blk->attn_img + (size_t)3 * C * C;
     GemmEpi e2 = {};
     e2.bias = blk->proj.b; e2.residual = x_in; e2.ldr = C; e2.out_f32 = x_out; e2.ldo = C;

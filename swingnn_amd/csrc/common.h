@@ -163,10 +163,17 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
 // wattn.hip : window attention core on a qkv buffer
 int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shift, int heads, int C, const float* rpb,
                       bf16* o, int ldo, hipStream_t s);
-// wattn_stream.hip : conditioning + LN1 + QKV + window attention for the wide stages (C = 384) -> o (bf16, pi slots)
-bool wattn_stream_supported(int C, int heads, int win);
-int launch_wattn_stream(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, bf16* o,
-                        int ldo, hipStream_t s);
+// wattn_fused.hip : conditioning + LN1 + QKV + window attention + proj + shortcut in one pass (C = 96)
+bool wattn_fused_supported(int C, int heads, int win);
+int launch_wattn_fused(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
+                       hipStream_t s);
+// wattn_ring.hip : conditioning + LN1 + QKV + window attention (+ proj + shortcut for C = 96 / 192) on a weight
+// fragment ring; C = 384 writes o (bf16, pi slots) for the projection GEMM
+bool wattn_ring_supported(int C, int heads, int win, int res);
+bool wattn_ring_fuses_proj(int C);
+bool wattn_ring_wants_xn(int C);
+int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* xn, int ldxn, const float* cond,
+                      int cond_stride, float* out, bf16* o, int ldo, hipStream_t s);
 // embed_mfma.hip : MFMA forms of patch embedding and final LN + read-out for p = 4, C0 = 96
 bool embed_mfma_supported(const swg_net* net);
 int launch_patch_embed_mfma(const swg_net* net, int B, const float* x, const float* sc, const float* c_in,
@@ -180,7 +187,3 @@ int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, 
 bool mlp_stream_supported(int C);
 int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                       const float* g, const float* b, hipStream_t s);
-// wattn_fused.hip : conditioning + LN1 + QKV + window attention + proj + shortcut in one pass (C = 96 / 192)
-bool wattn_fused_supported(int C, int heads, int win);
-int launch_wattn_fused(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
-                       hipStream_t s);

@@ -426,7 +426,7 @@ int launch_t(const FusedAttnArgs& a, size_t lds, int nwg, hipStream_t s) {
 }  // namespace
 
 bool wattn_fused_supported(int C, int heads, int win) {
-  return (C == 96 || C == 192) && heads * 32 == C && win == 6;  // 64-token windows need 2 waves per window (todo)
+  return C == 96 && heads * 32 == C && win == 6;  // 64-token windows need 2 waves per window (todo)
 }
 
 int launch_wattn_fused(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
@@ -444,7 +444,6 @@ int launch_wattn_fused(const swg_block* blk, int B, const float* x, const float*
   SwgProfScope ps(KID_FUSED_WATTN, 8.0 * T * C * C + 4.0 * T * n * C, 8.0 * T * C + 8.0 * C * C, s);
   int r;
   if (C == 96 && NTM == 3) r = launch_t<96, 3, false, 2>(a, lds, nwg, s);
-  else if (C == 192 && NTM == 3) r = launch_t<192, 3, false, 1>(a, lds, nwg, s);
   else return SWG_E_UNSUPPORTED;
   if (r) return r;
   SWG_LAUNCH_CHECK();

@@ -136,7 +136,7 @@ def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int) -> torch.Tenso
     return img.to(torch.bfloat16).contiguous()
 
 
-FUSED_ATTN_DIMS = (96, 192)
+FUSED_ATTN_DIMS = (96,)
 FUSED_ATTN_WINDOWS = (6,)
 USE_FUSED_ATTN = True
 
@@ -175,14 +175,15 @@ def wattn_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int) -> torch.
     return torch.cat(parts, dim=1).to(torch.bfloat16).contiguous()
 
 
-STREAM_ATTN_DIMS = (384,)
+RING_ATTN_FUSED_PROJ = {192: True, 384: False}  # csrc/wattn_ring.hip geometries
 
 
-def wattn_stream_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int) -> torch.Tensor:
-    """Weight image of csrc/wattn_stream.hip (head_dim 32): per head the slabs Wv, Wq, Wk (rows [32, C]) in MFMA
-    fragment order [k-step][16-row half][lane 16*lg + i][8] (lane holds row i, channels 32ks + 8lg ..+7), followed
-    by the projection weight [C, C] with its input columns in the order the kernel stores o: slot h*32 + 8lg + e
-    holds head dim pi(lg, e)."""
+def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse_proj: bool) -> torch.Tensor:
+    """Weight stream of csrc/wattn_ring.hip (head_dim 32) as 1-KiB MFMA fragments (lane 16*lg + i holds row i,
+    k-slots 8lg..8lg+7): per head the slabs Wv, Wq, Wk (rows [32, C]) as [k-step][16-row half][lane][8] and, when the
+    projection is fused, the Wproj column slice [C, 32] as [out tile][lane][8] with rows in rho order and the
+    head-dim slots in pi order.  Otherwise the projection weight [C, C] follows the stream, its input columns in
+    the order the kernel stores o (slot h*32 + 8lg + e holds head dim pi(lg, e))."""
     qkv_w, proj_w = qkv_w.detach().float(), proj_w.detach().float()
     Cdim = proj_w.shape[0]
     ks = Cdim // 32
@@ -191,20 +192,25 @@ def wattn_stream_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int) ->
     for part in (2, 0, 1):  # V, Q, K
         w = qkv_w[part * Cdim:(part + 1) * Cdim].reshape(heads, 2, 16, ks, 4, 8)   # [h, dt, i, ks, lg, e]
         slabs.append(w.permute(0, 3, 1, 4, 2, 5).reshape(heads, -1))               # [h, (ks, dt, lg, i, e)]
-    img = torch.stack(slabs, dim=1).reshape(-1)                                     # [h][V,Q,K][...]
-    wp = proj_w.reshape(Cdim, heads, 32)[..., _pi(dev)].reshape(Cdim, Cdim)
+    wp = proj_w.reshape(Cdim, heads, 32)[..., _pi(dev)]                             # [c, h, slot]
+    if fuse_proj:
+        w = wp[_rho(Cdim, dev)].reshape(Cdim // 16, 16, heads, 4, 8)                # [nt, i, h, lg, e]
+        slabs.append(w.permute(2, 0, 3, 1, 4).reshape(heads, -1))                   # [h, (nt, lg, i, e)]
+        return torch.stack(slabs, dim=1).reshape(-1).to(torch.bfloat16).contiguous()
+    img = torch.stack(slabs, dim=1).reshape(-1)
     return torch.cat([img, wp.reshape(-1)]).to(torch.bfloat16).contiguous()
 
 
 def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
     img = None
     aimg = None
-    if (USE_FUSED_ATTN and blk.dim in STREAM_ATTN_DIMS and blk.window_size == 6 and blk.dim // blk.num_heads == 32
-            and blk.input_resolution[0] % 6 == 0):
-        aimg = _ptr(keep(wattn_stream_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads)))
     if (USE_FUSED_ATTN and blk.dim in FUSED_ATTN_DIMS and blk.window_size in FUSED_ATTN_WINDOWS
             and blk.dim // blk.num_heads == 32):
         aimg = _ptr(keep(wattn_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads)))
+    elif (USE_FUSED_ATTN and blk.dim in RING_ATTN_FUSED_PROJ and blk.window_size == 6
+            and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % 6 == 0):
+        aimg = _ptr(keep(wattn_ring_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads,
+                                          RING_ATTN_FUSED_PROJ[blk.dim])))
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
         img = _ptr(keep(mlp_image(blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
     elif USE_FUSED_MLP and blk.dim in STREAM_MLP_HC:
