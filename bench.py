@@ -89,7 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=16, help="graphs per GPU per sample() call")
+    ap.add_argument("--batch", type=int, default=56,
+                    help="graphs per GPU per sample() call (56: the 128-token tiles of the C=384 stage fill 252 of 256 CUs)")
     ap.add_argument("--config", default="grid", choices=list(CONFIGS))
     ap.add_argument("--num-steps", type=int, default=256, help="Heun steps (256 = the shipped configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -157,7 +158,19 @@ def main():
         else:
             achieved = dom["bytes"] / dom["launches"] / avg_s / 1e9
             roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
-        roof.update(kernel=name, traffic=None, avg_launch_us=avg_s * 1e6, launches=dom["launches"],
+        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
+        # inside this process; scripts/pmc_traffic.sh collects them with the same batch).  null when no profile fits.
+        traffic, traffic_src = None, None
+        if args.config == "grid":
+            import glob
+            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+                prof_json = json.load(open(path))
+                if prof_json.get("batch", 56) == args.batch and name in prof_json["kernels"]:
+                    traffic = prof_json["kernels"][name]["hbm_bytes_per_launch"]
+                    traffic_src = os.path.relpath(path, ROOT) + ": " + prof_json["method"]
+                    break
+        roof.update(kernel=name, traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
+                    algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"], avg_launch_us=avg_s * 1e6, launches=dom["launches"],
                     share_of_gpu_time=dom["ms"] / total_ms,
                     tflops=dom["flops"] / (dom["ms"] * 1e-3) / 1e12, algorithmic_GBs=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
                     kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"],

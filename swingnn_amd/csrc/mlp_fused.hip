@@ -216,7 +216,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
 
 }  // namespace
 
-bool mlp_fused_supported(int C) { return C == 96 || C == 192; }
+bool mlp_fused_supported(int C) { return C == 96; }
 
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                      const float* g, const float* b, hipStream_t s) {

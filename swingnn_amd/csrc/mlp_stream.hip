@@ -66,6 +66,21 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
 #define STAGE_PIECE(chunk, buf_off, i)                                                        \
   lds_dma16(img_lane + (size_t)(chunk) * CHUNK_BYTES + ((i) * 4 + wave) * 1024,               \
             smem0 + (buf_off) + ((i) * 4 + wave) * 1024)
+  // the token rows are requested BEFORE the ring is primed: loads return in order, so rows issued behind two chunks
+  // of LDS-DMA would wait for them (C = 384: 192 registers of raw rows do not fit beside the LayerNorm temporaries)
+  constexpr bool ROWS_FIRST = C <= 192;
+  f32x4 xr[ROWS_FIRST ? 2 : 1][ROWS_FIRST ? KS : 1][2];
+  if (ROWS_FIRST) {
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const float* row = a.x + (size_t)min(tok0 + mt * 16 + l15, a.T - 1) * C + 8 * lg;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        xr[ROWS_FIRST ? mt : 0][ROWS_FIRST ? ks : 0][0] = *reinterpret_cast<const f32x4*>(row + 32 * ks);
+        xr[ROWS_FIRST ? mt : 0][ROWS_FIRST ? ks : 0][1] = *reinterpret_cast<const f32x4*>(row + 32 * ks + 4);
+      }
+    }
+  }
   float* sb1 = reinterpret_cast<float*>(smem + NBUF * CHUNK_BYTES);  // fc1 bias [4C] + 2 HC zeros (skew tail)
   for (int i = tid; i < 4 * C; i += 256) sb1[i] = a.b1[i];
   for (int i = tid; i < 2 * HC; i += 256) sb1[4 * C + i] = 0.f;
@@ -86,10 +101,16 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const float4 p0 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg);
-      const float4 p1 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg + 4);
-      v[ks][0] = p0.x; v[ks][1] = p0.y; v[ks][2] = p0.z; v[ks][3] = p0.w;
-      v[ks][4] = p1.x; v[ks][5] = p1.y; v[ks][6] = p1.z; v[ks][7] = p1.w;
+      f32x4 p0, p1;
+      if (ROWS_FIRST) {
+        p0 = xr[ROWS_FIRST ? mt : 0][ROWS_FIRST ? ks : 0][0];
+        p1 = xr[ROWS_FIRST ? mt : 0][ROWS_FIRST ? ks : 0][1];
+      } else {
+        p0 = *reinterpret_cast<const f32x4*>(row + 32 * ks + 8 * lg);
+        p1 = *reinterpret_cast<const f32x4*>(row + 32 * ks + 8 * lg + 4);
+      }
+      v[ks][0] = p0[0]; v[ks][1] = p0[1]; v[ks][2] = p0[2]; v[ks][3] = p0[3];
+      v[ks][4] = p1[0]; v[ks][5] = p1[1]; v[ks][6] = p1[2]; v[ks][7] = p1[3];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[ks][j];
     }
@@ -128,7 +149,8 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
   constexpr int NSL = 11 * NVEC;            // GELU slices (eleven levels per vector)
   constexpr int AHEAD = 6;                  // fragment reads in flight ahead of their MFMAs
   constexpr int DMA_EVERY = PAIRS / PIECES;
-  static_assert(PAIRS % PIECES == 0 && AHEAD < PAIRS && NSL <= PAIRS, "schedule shape");
+  constexpr int MAXS = (NSL + PAIRS - 1) / PAIRS;  // GELU slices per pair (VALU-bound geometries take several)
+  static_assert(PAIRS % PIECES == 0 && AHEAD < PAIRS, "schedule shape");
   f32x4 hcur[HT][2];   // fc1 output (+bias) of chunk j-1
   u32x4 hb[2][S2];     // GELU output of chunk j-2 as fc2 operand (packed bf16)
 #pragma unroll
@@ -189,8 +211,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
       if (p % DMA_EVERY == 1) STAGE_PIECE(next_chunk, prev, p / DMA_EVERY);
       // -- GELU of chunk j-1 (gelu_f of common.h, spelled out): vector t = ht*2+mt (4 independent values) advances
       //    one LEVEL per slice, the vectors take turns, so dependent VALU ops are several pairs apart
-      if (p < NSL) {  // one slice per pair (NSL <= PAIRS)
-        const int sl = p;
+#pragma unroll
+      for (int k = 0; k < MAXS; ++k) {
+        const int sl = p * NSL / PAIRS + k;
+        if (sl >= (p + 1) * NSL / PAIRS) continue;
         const int t = sl % NVEC, level = sl / NVEC, ht = t >> 1, mt = t & 1;
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -262,7 +286,7 @@ int launch_one(const MlpArgs& a, hipStream_t s) {
 
 }  // namespace
 
-bool mlp_stream_supported(int C) { return C == 384; }
+bool mlp_stream_supported(int C) { return C == 384 || C == 192; }
 
 int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                       const float* g, const float* b, hipStream_t s) {
@@ -270,7 +294,7 @@ int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img,
   if (T <= 0) return 0;
   MlpArgs a = {x, out, img, b1, b2, g, b, T};
   SwgProfScope ps(KID_FUSED_MLP, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
-  int rc = launch_one<384, 32, 3>(a, s);
+  int rc = (C == 384) ? launch_one<384, 32, 3>(a, s) : launch_one<192, 64, 3>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();
   return 0;

@@ -77,7 +77,7 @@ class Keep:
         return L.SwgLn(self.f32(mod.weight), self.f32(mod.bias))
 
 
-FUSED_MLP_DIMS = (96, 192)
+FUSED_MLP_DIMS = (96,)
 USE_FUSED_MLP = True
 
 
@@ -113,7 +113,7 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     return torch.cat([a, b], dim=1).to(torch.bfloat16).contiguous()
 
 
-STREAM_MLP_HC = {384: 32}  # hidden chunk width of csrc/mlp_stream.hip per channel count
+STREAM_MLP_HC = {384: 32, 192: 64}  # hidden chunk width of csrc/mlp_stream.hip per channel count
 
 
 def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int) -> torch.Tensor:
