@@ -89,8 +89,8 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=2)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=56,
-                    help="graphs per GPU per sample() call (56: the 128-token tiles of the C=384 stage fill 252 of 256 CUs)")
+    ap.add_argument("--batch", type=int, default=112,
+                    help="graphs per GPU per sample() call (multiples of 56 fill the 256 CUs with the 128-token tiles of the C=384 stage)")
     ap.add_argument("--config", default="grid", choices=list(CONFIGS))
     ap.add_argument("--num-steps", type=int, default=256, help="Heun steps (256 = the shipped configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")

@@ -5,9 +5,14 @@ from swingnn_amd import _lib as L, engine as E
 dev = 'cuda:0'
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 16
 shapes = []
-for (L0, C) in [(9216, 96), (2304, 192), (576, 384), (144, 768)]:
+for (L0, C) in [(576, 384), (144, 768)]:
     M = B * L0
     shapes += [(M, 3*C, C, 'qkv bf16'), (M, C, C, 'proj f32+res'), (M, 4*C, C, 'fc1 gelu bf16'), (M, C, 4*C, 'fc2 f32+res')]
+# merge (4C -> 2C at res/2) and breakup (pre: D -> D at res; post: D/4 -> D/4 at 2 res) linears of the grid net
+for (L0, C) in [(2304, 96), (576, 192), (144, 384)]:
+    shapes += [(B * L0, 2*C, 4*C, 'merge f32')]
+for (L0, D) in [(144, 1536), (576, 768), (2304, 384)]:
+    shapes += [(B * L0, D, D, 'pre f32'), (4 * B * L0, D // 4, D // 4, 'post f32')]
 shapes += [(8192, 8192, 4096, 'big bf16'), (8192, 8192, 4096, 'big f32')]
 for M, N, K, kind in shapes:
     a = torch.randn(M, K, device=dev).to(torch.bfloat16); w = (torch.randn(N, K, device=dev) * 0.05).to(torch.bfloat16)

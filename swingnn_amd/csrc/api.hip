@@ -158,8 +158,8 @@ int expand_impl(const swg_breakup* u, int B, const float* x, const float* skip, 
   GemmEpi e = {};
   e.out_f32 = y; e.ldo = Cin;
   if ((r = launch_gemm(cat, Kp, (const bf16*)u->pre.w, T, Cin, Kp, e, s))) return r;
-  if ((r = launch_ln_f32(y, T, Cin, u->ln.g, u->ln.b, y, s))) return r;  // in place: a row is read then written by its own lanes
-  if ((r = launch_breakup_ln(y, B, u->res, Co, u->post_ln.g, u->post_ln.b, sc, Cop, s))) return r;
+  // norm (over Cin) + 2x2 scatter + post_norm (over Co) in one pass over y
+  if ((r = launch_breakup_ln2(y, B, u->res, Cin, u->ln.g, u->ln.b, u->post_ln.g, u->post_ln.b, sc, Cop, s))) return r;
   GemmEpi e2 = {};
   e2.out_f32 = x_out; e2.ldo = Co;
   return launch_gemm(sc, Cop, (const bf16*)u->post.w, 4 * T, Co, Cop, e2, s);

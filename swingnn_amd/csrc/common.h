@@ -135,6 +135,8 @@ int launch_concat_cast(const float* a, const float* b, int rows, int Ch, bf16* o
 int launch_ln_f32(const float* x, int rows, int C, const float* g, const float* b, float* y, hipStream_t s);
 int launch_breakup_ln(const float* y, int B, int res, int Co, const float* g, const float* b, bf16* out, int ldo,
                       hipStream_t s);
+int launch_breakup_ln2(const float* y, int B, int res, int Cin, const float* g1, const float* b1, const float* g2,
+                       const float* b2, bf16* out, int ldo, hipStream_t s);
 int launch_gemv_rows(const float* W, const float* bias, const float* x, int Bx, int N, int K, int act, float* out,
                      hipStream_t s);
 int launch_pos_embed(const float* labels, int Bc, const float* freqs, int nf, float* out, hipStream_t s);

@@ -175,7 +175,10 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   const double osz = ee.out_f32 ? 4.0 : 2.0;
   SwgProfScope ps(KID_GEMM, 2.0 * M * (double)N * Kp,
                   2.0 * M * Kp + 2.0 * N * (double)Kp + osz * M * (double)N + (ee.residual ? 4.0 * M * (double)N : 0.0), s);
-  if (Kp % 64 == 0)
+  // BK = 32 halves the LDS footprint (4 workgroups per CU instead of 2): with many row panels in flight the extra
+  // residency hides the short-K prologue / epilogue better than the longer k-step amortises its barrier (measured
+  // per shape, scripts/bench_gemm.py: +5..25 % for M >= 32k, -3..10 % for M = 8k)
+  if (Kp % 64 == 0 && M < 16384)
     hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
   else
     hipLaunchKernelGGL(k_gemm_nt<32>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);

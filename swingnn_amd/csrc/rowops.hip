@@ -198,6 +198,112 @@ int launch_breakup_ln(const float* y, int B, int res, int Co, const float* g, co
 }
 
 // ------------------------------------------------------------------------------------------------
+// PatchBreakup middle (swin_gnn.py:385-399) in one pass: y row [Cin] -> LayerNorm(Cin) -> split into 4 sub-vectors of
+// Co = Cin/4 -> scatter to the 2x2 sub-tokens -> post_norm LayerNorm(Co) -> bf16 rows for the post_linear GEMM.
+// LANES lanes own one source row; lane g serves quarter g / (LANES/4), so the row statistics are a LANES-wide and
+// the sub-vector statistics a LANES/4-wide shuffle reduction, and y is read once (no in-place LN pass).
+// ------------------------------------------------------------------------------------------------
+struct Breakup2Args {
+  const float* y; const float* g1; const float* b1; const float* g2; const float* b2;
+  bf16* out;
+  int rows, res, Cin, Co, ldo;
+};
+
+template <int LANES, int V>
+__global__ __launch_bounds__(256) void k_breakup_ln2(Breakup2Args a) {
+  constexpr int RPB = 256 / LANES, Q = LANES / 4;
+  const int row = blockIdx.x * RPB + (int)threadIdx.x / LANES;
+  const int g = threadIdx.x % LANES;
+  if (row >= a.rows) return;
+  const int k = g / Q, jq = g % Q;  // quarter, lane inside the quarter
+  const int cq = a.Co >> 2;         // float4 chunks per quarter
+  const float* src = a.y + (size_t)row * a.Cin + k * a.Co;
+  float4 v[V];
+  float s = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int j = jq + i * Q;
+    v[i] = (j < cq) ? *reinterpret_cast<const float4*>(src + 4 * j) : make_float4(0.f, 0.f, 0.f, 0.f);
+    s += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+  }
+  const float mean = group_sum<LANES>(s) / (float)a.Cin;
+  float q = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+    if (jq + i * Q < cq) {
+      const float dx = v[i].x - mean, dy = v[i].y - mean, dz = v[i].z - mean, dw = v[i].w - mean;
+      q += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float rstd = ln_rstd(group_sum<LANES>(q) / (float)a.Cin);
+  float s2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int j = jq + i * Q;
+    if (j < cq) {
+      const float4 gg = *reinterpret_cast<const float4*>(a.g1 + k * a.Co + 4 * j);
+      const float4 bb = *reinterpret_cast<const float4*>(a.b1 + k * a.Co + 4 * j);
+      v[i].x = (v[i].x - mean) * rstd * gg.x + bb.x;
+      v[i].y = (v[i].y - mean) * rstd * gg.y + bb.y;
+      v[i].z = (v[i].z - mean) * rstd * gg.z + bb.z;
+      v[i].w = (v[i].w - mean) * rstd * gg.w + bb.w;
+      s2 += (v[i].x + v[i].y) + (v[i].z + v[i].w);
+    }
+  }
+  const float mean2 = group_sum<Q>(s2) / (float)a.Co;
+  float q2 = 0.f;
+#pragma unroll
+  for (int i = 0; i < V; ++i)
+    if (jq + i * Q < cq) {
+      const float dx = v[i].x - mean2, dy = v[i].y - mean2, dz = v[i].z - mean2, dw = v[i].w - mean2;
+      q2 += (dx * dx + dy * dy) + (dz * dz + dw * dw);
+    }
+  const float rstd2 = ln_rstd(group_sum<Q>(q2) / (float)a.Co);
+  // source token t = (b, y, x) on the res grid; quarter k goes to (2y+dy, 2x+dx): swin_gnn.py:389-397
+  const int bi = row / (a.res * a.res);
+  const int rem = row - bi * a.res * a.res;
+  const int yy = rem / a.res, xx = rem - yy * a.res;
+  const int dy = k & 1, dx = k >> 1;
+  const size_t drow = (size_t)bi * 4 * a.res * a.res + (size_t)(2 * yy + dy) * 2 * a.res + (2 * xx + dx);
+  const int nst = a.ldo >> 2;
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int j = jq + i * Q;
+    if (j < nst) {
+      uint2 o = make_uint2(0u, 0u);  // chunks in [cq, nst) are the zero K-padding of the following GEMM
+      if (j < cq) {
+        const float4 gg = *reinterpret_cast<const float4*>(a.g2 + 4 * j);
+        const float4 bb = *reinterpret_cast<const float4*>(a.b2 + 4 * j);
+        o = pack_bf16x4((v[i].x - mean2) * rstd2 * gg.x + bb.x, (v[i].y - mean2) * rstd2 * gg.y + bb.y,
+                        (v[i].z - mean2) * rstd2 * gg.z + bb.z, (v[i].w - mean2) * rstd2 * gg.w + bb.w);
+      }
+      *reinterpret_cast<uint2*>(a.out + drow * a.ldo + 4 * j) = o;
+    }
+  }
+}
+
+int launch_breakup_ln2(const float* y, int B, int res, int Cin, const float* g1, const float* b1, const float* g2,
+                       const float* b2, bf16* out, int ldo, hipStream_t s) {
+  if (Cin % 16 || ldo % 4) return SWG_E_SHAPE;
+  Breakup2Args a = {y, g1, b1, g2, b2, out, B * res * res, res, Cin, Cin / 4, ldo};
+  if (a.rows <= 0) return 0;
+  const int cq = ldo / 4;  // chunks to write per quarter
+  int lanes = 16;
+  while (lanes < 64 && cdiv(cq, lanes / 4) > 3) lanes *= 2;
+  const int v = cdiv(cq, lanes / 4);
+  SwgProfScope ps(KID_ROW_BREAKUP_LN, 0.0, 4.0 * a.rows * (double)Cin + 2.0 * a.rows * 4.0 * ldo, s);
+#define CALL(LN, VV) hipLaunchKernelGGL((k_breakup_ln2<LN, VV>), dim3(cdiv(a.rows, 256 / LN)), dim3(256), 0, s, a)
+  if (lanes == 16 && v <= 3) { if (v == 1) CALL(16, 1); else if (v == 2) CALL(16, 2); else CALL(16, 3); }
+  else if (lanes == 32 && v <= 3) { if (v == 1) CALL(32, 1); else if (v == 2) CALL(32, 2); else CALL(32, 3); }
+  else if (v <= 3) { if (v == 1) CALL(64, 1); else if (v == 2) CALL(64, 2); else CALL(64, 3); }
+  else if (v <= 6) CALL(64, 6);
+  else if (v <= 12) CALL(64, 12);
+  else return SWG_E_UNSUPPORTED;
+#undef CALL
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ------------------------------------------------------------------------------------------------
 // Noise embedding (swin_gnn.py:507-513, 757-760) and the stacked affine layers: three small GEMVs.
 // One wavefront per output feature; the weight row stays in registers while the batch is swept.
 // ------------------------------------------------------------------------------------------------
