@@ -61,8 +61,8 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
   if (r) return r;
   if (!x_in || !x_out || !cond) return SWG_E_NULL;
   const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C), ldq = ldq_of(C);
-  if (blk->attn_img && wattn_fused_supported(C, blk->heads, blk->win))
-    return launch_wattn_fused(blk, B, x_in, cond, cond_stride, x_out, s);
+  if (blk->attn_img && wattn_res_supported(C, blk->heads, blk->win, blk->res))
+    return launch_wattn_res(blk, B, x_in, cond, cond_stride, x_out, s);
   if (blk->attn_img && wattn_ring_supported(C, blk->heads, blk->win, blk->res)) {
     Carver cv(ws, ws_bytes);
     bf16* xn = nullptr;

@@ -165,10 +165,10 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
 // wattn.hip : window attention core on a qkv buffer
 int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shift, int heads, int C, const float* rpb,
                       bf16* o, int ldo, hipStream_t s);
-// wattn_fused.hip : conditioning + LN1 + QKV + window attention + proj + shortcut in one pass (C = 96)
-bool wattn_fused_supported(int C, int heads, int win);
-int launch_wattn_fused(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
-                       hipStream_t s);
+// wattn_res.hip : the same in one pass for C = 96 with all weights resident in LDS (persistent 8-wave workgroups)
+bool wattn_res_supported(int C, int heads, int win, int res);
+int launch_wattn_res(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
+                     hipStream_t s);
 // wattn_ring.hip : conditioning + LN1 + QKV + window attention (+ proj + shortcut for C = 96 / 192) on a weight
 // fragment ring; C = 384 writes o (bf16, pi slots) for the projection GEMM
 bool wattn_ring_supported(int C, int heads, int win, int res);

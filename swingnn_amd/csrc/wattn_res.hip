@@ -1,0 +1,410 @@
+// Window-attention half of a Swin block for the NARROW stage (C = 96, 3 heads, 6x6 windows; swin_gnn.py:238-272):
+//     x1 = silu(shift + x (1 + scale));  x_out = x1 + proj( softmax(q k^T * hd^-1/2 + bias + mask) v ),  qkv = Wqkv LN1(x1)
+// Same per-window data flow and pinned fragment groups as wattn_ring.hip, but all weights of the block (3 heads x 24
+// fragments = 72 KiB) stay RESIDENT in LDS: persistent workgroups of 8 waves copy them once by LDS-DMA, then every
+// wave walks over windows on its own -- no barrier, no DMA and no counted wait inside the window loop.  With two
+// waves per SIMD that drift apart, one wave's VALU phases (conditioning + LayerNorm1, softmax) overlap the other's
+// MFMA phases; at this width the kernel is bound by exactly those VALU phases and by the fp32 token stream.
+#include "common.h"
+
+namespace {
+
+struct ResAttnArgs {
+  const float* x;
+  float* out;
+  const float* cond;
+  int cond_stride, cond_off;
+  const float* ln_g;
+  const float* ln_b;
+  const bf16* img;      // fragment stream, engine.py wattn_ring_image(fuse_proj=True)
+  const float* qkv_b;   // [3C]
+  const float* proj_b;  // [C]
+  const float* rpb;     // [(2w-1)^2, heads]
+  int B, res, shift, heads;
+};
+
+template <int C, int NW, int AHEAD>
+__global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
+  constexpr int WIN = 6, NTOK = 36, NTM = 3, KSP = 2;
+  constexpr int KS = C / 32;
+  constexpr int NT = C / 16;
+  constexpr int SLAB = 2 * KS;           // fragments per slab (== NT)
+  constexpr int FRAGS_HEAD = 4 * SLAB;   // V, Q, K, P
+  constexpr int HEAD_BYTES = FRAGS_HEAD * 1024;
+  constexpr bool FUSE_PROJ = true;
+  static_assert(FRAGS_HEAD % (AHEAD + 1) == 0, "the register fragment ring must line up across heads");
+  constexpr int W2 = 2 * WIN - 1, NB = W2 * W2;
+  extern __shared__ __attribute__((aligned(16))) char smem[];
+  const int wbytes = a.heads * HEAD_BYTES;                            // resident weights (+ AHEAD KiB read-ahead slack)
+  float* s_qkvb = reinterpret_cast<float*>(smem + wbytes + AHEAD * 1024);  // [3C], q part pre-scaled
+  float* s_pb = s_qkvb + 3 * C;                                       // [C]
+  float* s_rpb = s_pb + C;                                            // [heads][NB] * log2(e)
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  const int nwx = a.res / WIN, nW = nwx * nwx;
+  const int total = a.B * nW;
+  const int Ltok = a.res * a.res;
+  constexpr float LOG2E = 1.44269504088896340736f;
+  constexpr float QSCALE = 0.17677669529663687f * LOG2E;  // 32^-0.5 * log2(e): scores live in the log2 domain
+
+  // ---- once per workgroup: weights -> LDS by LDS-DMA (1 KiB pieces round-robin over the waves), small tables ----
+  {
+    const unsigned smem0 = lds_addr(smem);
+    const char* img_lane = reinterpret_cast<const char*>(a.img) + lane * 16;
+    const int npieces = wbytes >> 10;
+    for (int pc = wave; pc < npieces; pc += NW) lds_dma16(img_lane + (size_t)pc * 1024, smem0 + pc * 1024);
+  }
+  for (int i = tid; i < 3 * C; i += 64 * NW) s_qkvb[i] = a.qkv_b[i] * (i < C ? QSCALE : 1.0f);
+  for (int i = tid; i < C; i += 64 * NW) s_pb[i] = a.proj_b[i];
+  for (int i = tid; i < NB * a.heads; i += 64 * NW) {
+    const int hh = i / NB, idx = i - hh * NB;
+    s_rpb[i] = a.rpb[idx * a.heads + hh] * LOG2E;
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+
+  // One issue group: fragment G of head h (compile-time G): {3 MFMAs, the ds_read of the fragment AHEAD later}.
+#define GROUP(G, BODY)                                                                                  \
+  {                                                                                                     \
+    const bf16x8 w = fr[(G) % (AHEAD + 1)];                                                             \
+    BODY;                                                                                               \
+    fr[((G) + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(cb + ((G) + AHEAD) * 1024);      \
+    __builtin_amdgcn_sched_barrier(0);                                                                  \
+  }
+
+  // ---- once per wave: the window-independent part of the token bookkeeping.  Query side: token i = mt*16 + l15;
+  // key side: token j = kt*16 + 4*lg + r.  iyx / kyx hold the in-window coordinates, qrel - krel the byte offset
+  // into a head's relative-position bias column (:110-121) ----
+  int iyx[NTM], kyx[NTM], qrel[NTM], krel[NTM][4];
+  const float kpad = (lg == 0) ? 0.f : -3.0e38f;  // last key tile: keys 32 + 4*lg + r exist only for lg == 0
+#pragma unroll
+  for (int mt = 0; mt < NTM; ++mt) {
+    const int i = min(mt * 16 + l15, NTOK - 1);
+    const int iy = i / WIN, ix = i - iy * WIN;
+    iyx[mt] = iy | (ix << 8);
+    qrel[mt] = 4 * ((iy + WIN - 1) * W2 + (ix + WIN - 1));
+    kyx[mt] = 0;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = min(mt * 16 + 4 * lg + r, NTOK - 1);
+      const int jy = j / WIN, jx = j - jy * WIN;
+      krel[mt][r] = 4 * (jy * W2 + jx);
+      kyx[mt] |= (jy | (jx << 3)) << (6 * r);
+    }
+  }
+
+  for (int wi_g = blockIdx.x * NW + wave; wi_g < total; wi_g += gridDim.x * NW) {
+    const bool live = true;
+    const int b = wi_g / nW, wi = wi_g - b * nW;
+    const int wy = wi / nwx, wx = wi - wy * nwx;
+    // region ids differ inside a window only in the last window row / column of a shifted block
+    const bool need_mask = __builtin_amdgcn_readfirstlane((int)(a.shift > 0 && (wy == nwx - 1 || wx == nwx - 1))) != 0;
+    // token rows of this window: shifted[y] = x[(y+s) mod H]  (roll by -s, :248)
+    int tokq[NTM];
+#pragma unroll
+    for (int mt = 0; mt < NTM; ++mt) {
+      int y = wy * WIN + (iyx[mt] & 255) + a.shift, x = wx * WIN + (iyx[mt] >> 8) + a.shift;
+      if (y >= a.res) y -= a.res;
+      if (x >= a.res) x -= a.res;
+      tokq[mt] = b * Ltok + y * a.res + x;
+    }
+    // ---- rows in operand layout: conditioning + SiLU, LayerNorm1 -> bf16 fragments (:238-244) ----
+    bf16x8 xa[NTM][KS];
+    // The projection accumulators START as shortcut + proj bias: accumulator row 4*lg+r of out tile nt = 2*ks+hh is
+    // channel 32ks + 8lg + 4hh + r (rho order of the image rows), i.e. exactly the channels this lane conditions
+    // below for k-step ks, so the epilogue is a plain store (no second pass over x, no second SiLU).
+    f32x4 acc[NT][NTM];
+    const float* crow = a.cond + (size_t)b * a.cond_stride + a.cond_off;
+#pragma unroll
+    for (int mt = 0; mt < NTM; ++mt) {
+      const float* row = a.x + (size_t)tokq[mt] * C;
+      float x1[KS][8];
+      float s = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c0 = 32 * ks + 8 * lg;
+        const float4 p0 = *reinterpret_cast<const float4*>(row + c0);
+        const float4 p1 = *reinterpret_cast<const float4*>(row + c0 + 4);
+        const float4 sc0 = *reinterpret_cast<const float4*>(crow + c0);
+        const float4 sc1 = *reinterpret_cast<const float4*>(crow + c0 + 4);
+        const float4 sh0 = *reinterpret_cast<const float4*>(crow + C + c0);
+        const float4 sh1 = *reinterpret_cast<const float4*>(crow + C + c0 + 4);
+        const float xv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
+        const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
+        const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        const float4 pb0 = *reinterpret_cast<const float4*>(s_pb + c0);
+        const float4 pb1 = *reinterpret_cast<const float4*>(s_pb + c0 + 4);
+        const float pb[8] = {pb0.x, pb0.y, pb0.z, pb0.w, pb1.x, pb1.y, pb1.z, pb1.w};
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          const float v = silu_f(sh[j] + xv[j] * (sc[j] + 1.f));
+          x1[ks][j] = v;
+          s += v;
+          acc[2 * ks + (j >> 2)][mt][j & 3] = v + pb[j];
+        }
+      }
+      s = rows_sum(s);
+      const float mean = s * (1.0f / C);
+      float q = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int j = 0; j < 8; ++j) { const float d = x1[ks][j] - mean; q += d * d; }
+      q = rows_sum(q);
+      const float rstd = ln_rstd(q * (1.0f / C));
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const int c0 = 32 * ks + 8 * lg;
+        const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + c0);
+        const float4 g1 = *reinterpret_cast<const float4*>(a.ln_g + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + c0);
+        const float4 b1 = *reinterpret_cast<const float4*>(a.ln_b + c0 + 4);
+        const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
+        const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
+        bf16x8 f;
+#pragma unroll
+        for (int j = 0; j < 8; ++j) f[j] = (bf16)((x1[ks][j] - mean) * rstd * gg[j] + bb[j]);
+        xa[mt][ks] = f;
+      }
+    }
+    asm volatile("" ::: "memory");
+    // region ids (swin_gnn.py:207-226) of the lane's query row (bits 0..3) and its 4 keys (bits 4+4r..), per token
+    // tile: only needed in the border windows of a shifted block
+    int rids[NTM];
+    if (need_mask) {
+#pragma unroll
+      for (int mt = 0; mt < NTM; ++mt) {
+        auto region = [&](int iy, int ix) {
+          const int ys = wy * WIN + iy, xs = wx * WIN + ix;
+          const int ry = ys < a.res - WIN ? 0 : (ys < a.res - a.shift ? 1 : 2);
+          const int rx = xs < a.res - WIN ? 0 : (xs < a.res - a.shift ? 1 : 2);
+          return 3 * ry + rx;
+        };
+        rids[mt] = region(iyx[mt] & 255, iyx[mt] >> 8);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int kk = (kyx[mt] >> (6 * r)) & 63;
+          rids[mt] |= region(kk & 7, kk >> 3) << (4 + 4 * r);
+        }
+      }
+    } else {
+#pragma unroll
+      for (int mt = 0; mt < NTM; ++mt) rids[mt] = 0;
+    }
+    bf16x8 fr[AHEAD + 1];
+#pragma unroll
+    for (int p = 0; p < AHEAD; ++p) fr[p] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + p * 1024);
+
+#pragma nounroll
+    for (int h = 0; h < a.heads; ++h) {
+      const char* cb = smem + h * HEAD_BYTES + lane * 16;  // fragments are contiguous across heads
+      // ---- V [tokens x 32] = A Wv^T (tokens on rows: directly the A operand of O^T = V^T P^T) ----
+      bf16x8 qf[NTM], kf[NTM], vf[2][KSP];
+      {
+        f32x4 va[NTM][2];
+#pragma unroll
+        for (int mt = 0; mt < NTM; ++mt)
+#pragma unroll
+          for (int dt = 0; dt < 2; ++dt) va[mt][dt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < SLAB; ++p) {
+          GROUP(p, _Pragma("unroll") for (int mt = 0; mt < NTM; ++mt) va[mt][p & 1] =
+                       __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[mt][p >> 1], w, va[mt][p & 1], 0, 0, 0));
+        }
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const float bv = s_qkvb[2 * C + h * 32 + dt * 16 + l15];
+#pragma unroll
+          for (int ks = 0; ks < KSP; ++ks) {
+            bf16x8 f;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+              f[j] = (bf16)(va[2 * ks][dt][j] + bv);
+              f[4 + j] = (2 * ks + 1 < NTM) ? (bf16)(va[(2 * ks + 1 < NTM) ? 2 * ks + 1 : 0][dt][j] + bv) : (bf16)0.f;
+            }
+            vf[dt][ks] = f;
+          }
+        }
+      }
+        // ---- Q^T, K^T [32 x tokens] = W A^T ; k-slot j of lane group lg is head dim (j<4 ? 4lg+j : 16+4lg+j-4) ----
+      {
+        f32x4 qa[2][NTM];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int mt = 0; mt < NTM; ++mt) qa[dt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < SLAB; ++p) {
+          GROUP(SLAB + p, _Pragma("unroll") for (int mt = 0; mt < NTM; ++mt) qa[p & 1][mt] =
+                              __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xa[mt][p >> 1], qa[p & 1][mt], 0, 0, 0));
+        }
+        const float4 bq0 = *reinterpret_cast<const float4*>(s_qkvb + h * 32 + 4 * lg);
+        const float4 bq1 = *reinterpret_cast<const float4*>(s_qkvb + h * 32 + 16 + 4 * lg);
+#pragma unroll
+        for (int mt = 0; mt < NTM; ++mt) {
+          bf16x8 f;
+          f[0] = (bf16)fmaf(qa[0][mt][0], QSCALE, bq0.x); f[1] = (bf16)fmaf(qa[0][mt][1], QSCALE, bq0.y);
+          f[2] = (bf16)fmaf(qa[0][mt][2], QSCALE, bq0.z); f[3] = (bf16)fmaf(qa[0][mt][3], QSCALE, bq0.w);
+          f[4] = (bf16)fmaf(qa[1][mt][0], QSCALE, bq1.x); f[5] = (bf16)fmaf(qa[1][mt][1], QSCALE, bq1.y);
+          f[6] = (bf16)fmaf(qa[1][mt][2], QSCALE, bq1.z); f[7] = (bf16)fmaf(qa[1][mt][3], QSCALE, bq1.w);
+          qf[mt] = f;
+        }
+      }
+      {
+        f32x4 ka[2][NTM];
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+          for (int mt = 0; mt < NTM; ++mt) ka[dt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int p = 0; p < SLAB; ++p) {
+          GROUP(2 * SLAB + p, _Pragma("unroll") for (int mt = 0; mt < NTM; ++mt) ka[p & 1][mt] =
+                                  __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xa[mt][p >> 1], ka[p & 1][mt], 0, 0, 0));
+        }
+        const float4 bk0 = *reinterpret_cast<const float4*>(s_qkvb + C + h * 32 + 4 * lg);
+        const float4 bk1 = *reinterpret_cast<const float4*>(s_qkvb + C + h * 32 + 16 + 4 * lg);
+#pragma unroll
+        for (int mt = 0; mt < NTM; ++mt) {
+          bf16x8 g;
+          g[0] = (bf16)(ka[0][mt][0] + bk0.x); g[1] = (bf16)(ka[0][mt][1] + bk0.y);
+          g[2] = (bf16)(ka[0][mt][2] + bk0.z); g[3] = (bf16)(ka[0][mt][3] + bk0.w);
+          g[4] = (bf16)(ka[1][mt][0] + bk1.x); g[5] = (bf16)(ka[1][mt][1] + bk1.y);
+          g[6] = (bf16)(ka[1][mt][2] + bk1.z); g[7] = (bf16)(ka[1][mt][3] + bk1.w);
+          kf[mt] = g;
+        }
+      }
+
+        // ---- S^T = K Q^T (log2 domain), softmax over keys (rows) per query (lane) ----
+      float p[NTM][NTM][4];
+#pragma unroll
+      for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NTM; ++qt) {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], z, 0, 0, 0);
+          p[kt][qt][0] = z[0]; p[kt][qt][1] = z[1]; p[kt][qt][2] = z[2]; p[kt][qt][3] = z[3];
+        }
+      const char* rp = reinterpret_cast<const char*>(s_rpb + h * NB);
+#pragma unroll
+      for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NTM; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = p[kt][qt][r] + *reinterpret_cast<const float*>(rp + (qrel[qt] - krel[kt][r]));
+            if (kt == NTM - 1) sv += kpad;
+            p[kt][qt][r] = sv;
+          }
+      if (need_mask) {  // wave-uniform: only the border windows of shifted blocks pay for the region mask (:207-226)
+#pragma unroll
+        for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+          for (int qt = 0; qt < NTM; ++qt)
+#pragma unroll
+            for (int r = 0; r < 4; ++r)
+              if (((rids[kt] >> (4 + 4 * r)) & 15) != (rids[qt] & 15)) p[kt][qt][r] += -100.0f * LOG2E;
+      }
+      float inv_sum[NTM];
+#pragma unroll
+      for (int qt = 0; qt < NTM; ++qt) {
+        float mx = -3.0e38f;
+#pragma unroll
+        for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) mx = fmaxf(mx, p[kt][qt][r]);
+        mx = rows_max(mx);
+        float sum = 0.f;
+#pragma unroll
+        for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const float e = __builtin_amdgcn_exp2f(p[kt][qt][r] - mx);  // padding keys: exp2(-huge) = 0
+            p[kt][qt][r] = e;
+            sum += e;
+          }
+        sum = rows_sum(sum);
+        inv_sum[qt] = __frcp_rn(sum);
+      }
+
+      // ---- O^T = V^T P^T ; channel slot h*32 + 8*lg + e of a row holds head dim pi(lg, e) ----
+      bf16x8 of[NTM];
+#pragma unroll
+      for (int qt = 0; qt < NTM; ++qt) {
+        bf16x8 pf[KSP];
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) {
+          bf16x8 f;
+#pragma unroll
+          for (int j = 0; j < 4; ++j) {
+            f[j] = (bf16)p[2 * ks][qt][j];
+            f[4 + j] = (2 * ks + 1 < NTM) ? (bf16)p[(2 * ks + 1 < NTM) ? 2 * ks + 1 : 0][qt][j] : (bf16)0.f;
+          }
+          pf[ks] = f;
+        }
+        f32x4 o0 = {0.f, 0.f, 0.f, 0.f}, o1 = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < KSP; ++ks) {
+          o0 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[0][ks], pf[ks], o0, 0, 0, 0);
+          o1 = __builtin_amdgcn_mfma_f32_16x16x32_bf16(vf[1][ks], pf[ks], o1, 0, 0, 0);
+        }
+        const float is = inv_sum[qt];
+        bf16x8 f;
+        f[0] = (bf16)(o0[0] * is); f[1] = (bf16)(o0[1] * is); f[2] = (bf16)(o0[2] * is); f[3] = (bf16)(o0[3] * is);
+        f[4] = (bf16)(o1[0] * is); f[5] = (bf16)(o1[1] * is); f[6] = (bf16)(o1[2] * is); f[7] = (bf16)(o1[3] * is);
+        of[qt] = f;
+      }
+        {
+        // ---- out^T += Wp_h O^T (Wproj columns carry the head-dim slot order, rows the rho order, in the image) ----
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int p2 = 0; p2 < SLAB; ++p2) {
+          GROUP(3 * SLAB + p2, _Pragma("unroll") for (int mt = 0; mt < NTM; ++mt) acc[p2][mt] =
+                                   __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, of[mt], acc[p2][mt], 0, 0, 0));
+        }
+      }
+    }
+
+    // ---- epilogue: scatter back to token order (shortcut and bias are already in the accumulators) ----
+#pragma unroll
+    for (int mt = 0; mt < NTM; ++mt) {
+      if (mt * 16 + l15 >= NTOK) continue;
+      float* orow = a.out + (size_t)tokq[mt] * C;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<f32x4*>(orow + 32 * (nt >> 1) + 8 * lg + 4 * (nt & 1)) = acc[nt][mt];
+    }
+  }
+#undef GROUP
+}
+
+}  // namespace
+
+bool wattn_res_supported(int C, int heads, int win, int res) {
+  return C == 96 && heads == 3 && win == 6 && res % 6 == 0;
+}
+
+int launch_wattn_res(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
+                     hipStream_t s) {
+  if (!wattn_res_supported(blk->C, blk->heads, blk->win, blk->res) || !blk->attn_img) return SWG_E_UNSUPPORTED;
+  constexpr int C = 96, NW = 8, AHEAD = 3;
+  const int nW = (blk->res / blk->win) * (blk->res / blk->win);
+  ResAttnArgs a = {x, out, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, (const bf16*)blk->attn_img,
+                   blk->qkv.b, blk->proj.b, blk->rpb, B, blk->res, blk->shift, blk->heads};
+  const size_t lds = (size_t)blk->heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 +
+                     (size_t)(4 * C + 121 * blk->heads) * sizeof(float);
+  const int total = B * nW;
+  const int nwg = min(cdiv(total, NW), 256);
+  const double T = (double)B * blk->res * blk->res;
+  SwgProfScope ps(KID_FUSED_WATTN, 8.0 * T * C * C + 4.0 * T * 36 * C, 8.0 * T * C + 8.0 * C * C, s);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_res<C, NW, AHEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                       (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_wattn_res<C, NW, AHEAD>), dim3(nwg), dim3(64 * NW), lds, s, a);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}

@@ -136,8 +136,6 @@ def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int) -> torch.Tenso
     return img.to(torch.bfloat16).contiguous()
 
 
-FUSED_ATTN_DIMS = (96,)
-FUSED_ATTN_WINDOWS = (6,)
 USE_FUSED_ATTN = True
 
 
@@ -158,24 +156,7 @@ def _pi(device) -> torch.Tensor:
     return torch.where(e < 4, 4 * ch + e, 16 + 4 * ch + e - 4).reshape(-1)
 
 
-def wattn_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int) -> torch.Tensor:
-    """Weight image of the fused window-attention kernel (csrc/wattn_fused.hip), head_dim 32: per head the
-    Wq, Wk, Wv row slices [32, C] as [k-step][row][4 slots][8] and the Wproj column slice [C, 32] as
-    [row rho][4 slots][8] with the head-dim slot order pi."""
-    qkv_w, proj_w = qkv_w.detach().float(), proj_w.detach().float()
-    Cdim = proj_w.shape[0]
-    ks = Cdim // 32
-    dev = qkv_w.device
-    parts = []
-    for part in range(3):
-        w = qkv_w[part * Cdim:(part + 1) * Cdim].reshape(heads, 32, ks, 4, 8).permute(0, 2, 1, 3, 4)  # [h, s, d, ch, e]
-        parts.append(_slot_swizzle(w.contiguous()).reshape(heads, -1))
-    wp = proj_w[_rho(Cdim, dev)].reshape(Cdim, heads, 32)[..., _pi(dev)].reshape(Cdim, heads, 4, 8).permute(1, 0, 2, 3)
-    parts.append(_slot_swizzle(wp.contiguous()).reshape(heads, -1))
-    return torch.cat(parts, dim=1).to(torch.bfloat16).contiguous()
-
-
-RING_ATTN_FUSED_PROJ = {192: True, 384: False}  # csrc/wattn_ring.hip geometries
+RING_ATTN_FUSED_PROJ = {96: True, 192: True, 384: False}  # 96: wattn_res.hip (weights resident in LDS)  # csrc/wattn_ring.hip geometries
 
 
 def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse_proj: bool) -> torch.Tensor:
@@ -204,10 +185,7 @@ def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse
 def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
     img = None
     aimg = None
-    if (USE_FUSED_ATTN and blk.dim in FUSED_ATTN_DIMS and blk.window_size in FUSED_ATTN_WINDOWS
-            and blk.dim // blk.num_heads == 32):
-        aimg = _ptr(keep(wattn_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads)))
-    elif (USE_FUSED_ATTN and blk.dim in RING_ATTN_FUSED_PROJ and blk.window_size == 6
+    if (USE_FUSED_ATTN and blk.dim in RING_ATTN_FUSED_PROJ and blk.window_size == 6
             and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % 6 == 0):
         aimg = _ptr(keep(wattn_ring_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads,
                                           RING_ATTN_FUSED_PROJ[blk.dim])))
