@@ -158,6 +158,9 @@ int expand_impl(const swg_breakup* u, int B, const float* x, const float* skip, 
   GemmEpi e = {};
   e.out_f32 = y; e.ldo = Cin;
   if ((r = launch_gemm(cat, Kp, (const bf16*)u->pre.w, T, Cin, Kp, e, s))) return r;
+  if (breakup_post_supported(Co))  // ... and post_linear too, when its weight fits the register file
+    return launch_breakup_post(y, B, u->res, Co, u->ln.g, u->ln.b, u->post_ln.g, u->post_ln.b, (const bf16*)u->post.w,
+                               u->post.Kp, x_out, s);
   // norm (over Cin) + 2x2 scatter + post_norm (over Co) in one pass over y
   if ((r = launch_breakup_ln2(y, B, u->res, Cin, u->ln.g, u->ln.b, u->post_ln.g, u->post_ln.b, sc, Cop, s))) return r;
   GemmEpi e2 = {};

@@ -181,6 +181,10 @@ bool embed_mfma_supported(const swg_net* net);
 int launch_patch_embed_mfma(const swg_net* net, int B, const float* x, const float* sc, const float* c_in,
                             int c_in_stride, const float* cond, int cond_stride, float* tok, hipStream_t s);
 int launch_final_readout_mfma(const swg_net* net, int B, const float* tok, float* F, hipStream_t s);
+// PatchBreakup tail (norm + scatter + post_norm + post_linear) in one pass, Co = 96
+bool breakup_post_supported(int Co);
+int launch_breakup_post(const float* y, int B, int res, int Co, const float* g1, const float* b1, const float* g2,
+                        const float* b2, const bf16* w, int ldw, float* out, hipStream_t s);
 // mlp_fused.hip : x_out = x + fc2(GELU(fc1(LN2(x)))) in one pass (C = 96 / 192)
 bool mlp_fused_supported(int C);
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,

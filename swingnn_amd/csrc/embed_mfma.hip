@@ -199,6 +199,110 @@ __global__ __launch_bounds__(256) void k_final_readout_mfma(ReadoutMfmaArgs a) {
   }
 }
 
+// PatchBreakup tail (swin_gnn.py:385-403) in ONE pass for Co = 96 (Cin = 384):
+//   y row [Cin] -> norm LayerNorm(Cin) -> 4 sub-vectors of Co -> 2x2 scatter -> post_norm LayerNorm(Co) -> post_linear (no
+//   bias) -> fp32 token rows.  The 96x96 weight lives in registers as 18 MFMA fragments per wave (persistent waves);
+//   a wave takes 16 source tokens at a time, token on the lane.  Replaces k_breakup_ln2 + a [4T,96]x[96,96] GEMM whose
+//   bf16 operand round trip cost more than the product.
+struct BreakupPostArgs {
+  const float* y; const float* g1; const float* b1; const float* g2; const float* b2;
+  const bf16* w;   // post_linear weight, bf16 [Co, ldw]
+  int ldw;
+  float* out;      // [4 * rows, Co]
+  int rows, res;
+};
+
+template <int CO>
+__global__ __launch_bounds__(256) void k_breakup_post(BreakupPostArgs a) {
+  constexpr int KS = CO / 32, NT = CO / 16, CIN = 4 * CO;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int l15 = lane & 15, lg = lane >> 4;
+  bf16x8 wf[NT][KS];  // A operand: row = out channel rho(nt*16 + l15), k-slots = input channels 32ks + 8lg ..+7
+#pragma unroll
+  for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+    for (int ks = 0; ks < KS; ++ks)
+      wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)rho_chan(nt, l15) * a.ldw + 32 * ks + 8 * lg);
+  const int ntiles = (a.rows + 15) >> 4;
+  const int L = a.res * a.res;
+  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
+    const int row = min(tile * 16 + l15, a.rows - 1);
+    const float* src = a.y + (size_t)row * CIN + 8 * lg;
+    float v[4][KS][8];
+    float s = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f32x4 p0 = *reinterpret_cast<const f32x4*>(src + k * CO + 32 * ks);
+        const f32x4 p1 = *reinterpret_cast<const f32x4*>(src + k * CO + 32 * ks + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) { v[k][ks][e] = p0[e]; v[k][ks][4 + e] = p1[e]; s += p0[e] + p1[e]; }
+      }
+    const float mean = rows_sum(s) * (1.0f / CIN);
+    float q = 0.f;
+#pragma unroll
+    for (int k = 0; k < 4; ++k)
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[k][ks][e] - mean; q += d * d; }
+    const float rstd = ln_rstd(rows_sum(q) * (1.0f / CIN));
+    const int bi = row / L, rem = row - bi * L;
+    const int yy = rem / a.res, xx = rem - yy * a.res;
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+      // norm (its affine parameters are indexed by the position in the Cin row), then the sub-vector statistics
+      float s2 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.g1 + k * CO + 32 * ks + 8 * lg);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(a.g1 + k * CO + 32 * ks + 8 * lg + 4);
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b1 + k * CO + 32 * ks + 8 * lg);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b1 + k * CO + 32 * ks + 8 * lg + 4);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          v[k][ks][e] = (v[k][ks][e] - mean) * rstd * ga[e] + ba[e];
+          v[k][ks][4 + e] = (v[k][ks][4 + e] - mean) * rstd * gb[e] + bb[e];
+          s2 += v[k][ks][e] + v[k][ks][4 + e];
+        }
+      }
+      const float mean2 = rows_sum(s2) * (1.0f / CO);
+      float q2 = 0.f;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) { const float d = v[k][ks][e] - mean2; q2 += d * d; }
+      const float rstd2 = ln_rstd(rows_sum(q2) * (1.0f / CO));
+      f32x4 acc[NT];
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.g2 + 32 * ks + 8 * lg);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(a.g2 + 32 * ks + 8 * lg + 4);
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg + 4);
+        bf16x8 f;
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          f[e] = (bf16)((v[k][ks][e] - mean2) * rstd2 * ga[e] + ba[e]);
+          f[4 + e] = (bf16)((v[k][ks][4 + e] - mean2) * rstd2 * gb[e] + bb[e]);
+        }
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wf[nt][ks], f, acc[nt], 0, 0, 0);
+      }
+      if (tile * 16 + l15 < a.rows) {
+        // quarter k of token (b, y, x) is sub-token (2y + dy, 2x + dx), (dy, dx) = (k & 1, k >> 1): swin_gnn.py:389-397
+        const size_t drow = (size_t)bi * 4 * L + (size_t)(2 * yy + (k & 1)) * 2 * a.res + (2 * xx + (k >> 1));
+        float* orow = a.out + drow * CO;
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) *reinterpret_cast<f32x4*>(orow + rho_chan(nt, 4 * lg)) = acc[nt];
+      }
+    }
+  }
+}
+
 int persistent_grid(int ntiles) { return max(1, min(cdiv(ntiles, 4), 256 * 8)); }
 
 }  // namespace
@@ -224,6 +328,19 @@ int launch_final_readout_mfma(const swg_net* net, int B, const float* tok, float
   const int hp = net->N / 4, rows = B * hp * hp;
   SwgProfScope ps(KID_READOUT, 2.0 * rows * 96.0 * 16, 4.0 * rows * 96.0 + 4.0 * B * (double)net->N * net->N, s);
   hipLaunchKernelGGL((k_final_readout_mfma<96>), dim3(persistent_grid(cdiv(rows, 16))), dim3(256), 0, s, a);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+bool breakup_post_supported(int Co) { return Co == 96; }
+
+int launch_breakup_post(const float* y, int B, int res, int Co, const float* g1, const float* b1, const float* g2,
+                        const float* b2, const bf16* w, int ldw, float* out, hipStream_t s) {
+  if (!breakup_post_supported(Co) || ldw % 8) return SWG_E_UNSUPPORTED;
+  BreakupPostArgs a = {y, g1, b1, g2, b2, w, ldw, out, B * res * res, res};
+  if (a.rows <= 0) return 0;
+  SwgProfScope ps(KID_ROW_BREAKUP_LN, 2.0 * 4.0 * a.rows * (double)Co * Co, 2.0 * 4.0 * a.rows * 4.0 * Co, s);
+  hipLaunchKernelGGL((k_breakup_post<96>), dim3(persistent_grid((a.rows + 15) / 16)), dim3(256), 0, s, a);
   SWG_LAUNCH_CHECK();
   return 0;
 }

@@ -91,8 +91,11 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
     for (int i = 0; i < PIECES; ++i) STAGE_PIECE(1, CHUNK_BYTES, i);
   }
 
-  // ---- the wave's 32 token rows in operand layout, LayerNorm2 in registers ----
+  // ---- the wave's 32 token rows in operand layout, LayerNorm2 in registers.  The fc2 accumulators START as
+  // residual + fc2 bias: accumulator row 4*lg+r of out tile nt = 2*ks+hh is channel 32ks + 8lg + 4hh + r (rho order of
+  // the image rows), the channels this lane loads for k-step ks, so the epilogue is a plain store ----
   bf16x8 xa[2][KS];
+  f32x4 acc[NT][2];
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
@@ -113,6 +116,10 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
       v[ks][4] = p1[0]; v[ks][5] = p1[1]; v[ks][6] = p1[2]; v[ks][7] = p1[3];
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[ks][j];
+      const f32x4 c0 = *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg);
+      const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg + 4);
+      acc[2 * ks][mt] = p0 + c0;
+      acc[2 * ks + 1][mt] = p1 + c1;
     }
     s = rows_sum(s);
     const float mean = s * (1.0f / C);
@@ -138,11 +145,6 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
     }
   }
 
-  f32x4 acc[NT][2];
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   constexpr int NV = HT * 2 * 4;           // GELU evaluations per lane per chunk
   constexpr int PAIRS = KS * HT + S2 * NT;  // weight fragments == MFMA pairs per iteration
   constexpr int NVEC = HT * 2;              // ... as f32x4 accumulator vectors
@@ -249,24 +251,14 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
 #undef STAGE_PIECE
   wait_vmcnt<0>();  // the trailing refills must have landed before the workgroup's LDS is released
 
-  // ---- epilogue: + b2 + residual (re-read, L2/MALL-warm), fp32 store.  fc2 image rows are rho-ordered: accumulator
-  // row 4*lg+r of tile nt = 2*ks+hh is channel 32*ks + 8*lg + 4*hh + r, so a lane stores 32 contiguous bytes.
+  // ---- epilogue: the accumulators hold x + b2 + fc2(...): a lane stores 32 contiguous bytes per k-step ----
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int tok = tok0 + mt * 16 + l15;
     if (tok >= a.T) continue;
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt) {
-      const int c = 32 * (nt >> 1) + 8 * lg + 4 * (nt & 1);
-      const float4 bb = *reinterpret_cast<const float4*>(a.b2 + c);
-      const float4 r4 = *reinterpret_cast<const float4*>(a.x + (size_t)tok * C + c);
-      float4 o;
-      o.x = acc[nt][mt][0] + bb.x + r4.x;
-      o.y = acc[nt][mt][1] + bb.y + r4.y;
-      o.z = acc[nt][mt][2] + bb.z + r4.z;
-      o.w = acc[nt][mt][3] + bb.w + r4.w;
-      *reinterpret_cast<float4*>(a.out + (size_t)tok * C + c) = o;
-    }
+    for (int nt = 0; nt < NT; ++nt)
+      *reinterpret_cast<f32x4*>(a.out + (size_t)tok * C + 32 * (nt >> 1) + 8 * lg + 4 * (nt & 1)) = acc[nt][mt];
   }
 }
 
