@@ -180,6 +180,23 @@ int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_pr
 int swg_mask_adjs(int32_t B, int32_t N, float* a, const float* node_flags, void* stream);
 int swg_sym_check(int32_t B, int32_t N, const float* a, float* acc, void* stream);
 
+/* ---- EDM training objective and loss, forward only ---- */
+/* runner/objectives/edm.py:160-212 (get_input_output with sigma_dist = precond = 'edm'), randn draws factored out:
+ *   sigma = exp(1.2 r - 1.2), w = (sigma^2 + 1/4) / (sigma/2)^2 (:174-176), noisy = mask(clean + sigma sym(raw)),
+ *   noise_added = mask(sigma sym(raw)) (:181-186 -> utils/graph_utils.py:122-152), and the preconditioning scalars of
+ *   :122-126.  noise_added and the four c_* outputs may be NULL.  rnd_normal, sigmas, weights, c_*: [B]. */
+int swg_edm_objective(int32_t B, int32_t N, const float* clean, const float* node_flags, const float* rnd_normal,
+                      const float* raw_noise, float* noisy, float* noise_added, float* sigmas, float* weights,
+                      float* c_skip, float* c_out, float* c_in, float* c_noise, void* stream);
+/* loss/rainbow_loss.py:84-111, objective 'edm', no reweighting:  S_b = w_b sum_ij mask (pred - target)^2,
+ *   reduction 'none' (reduction_mean = 0): loss_b = S_b / (sum flags_b)^2 * regression_loss_weight
+ *   reduction 'mean' (:94-96, = 1):        loss_b = (sum_b S_b) / (sum flags_b)^2 * regression_loss_weight
+ * weights may be NULL (ones).  scratch2B: 2*B floats of device scratch.  Deterministic summation order. */
+int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, const float* node_flags,
+                 const float* weights, float regression_loss_weight, int32_t reduction_mean, float* loss,
+                 float* scratch2B, void* stream);
+
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------------------- *
  * When enabled, every internal kernel launch is bracketed by HIP events on its stream and its
  * algorithmic FLOPs / bytes are tallied per kernel.  swg_prof_read synchronises the recorded events.

@@ -9,6 +9,7 @@ from .swin_gnn import (SwinGNN, SwinTransformerBlock, WindowAttention, PatchMerg
                        BasicLayer, Mlp, PositionalEmbedding)
 from .precond import Precond
 from .edm_sampler import EDMSampler, GeneralSampler
+from .objective import EDMObjectiveGenerator, RainbowLoss
 
 __all__ = ["SwinGNN", "SwinTransformerBlock", "WindowAttention", "PatchMerging", "PatchBreakup", "PatchEmbed",
-           "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler"]
+           "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler", "EDMObjectiveGenerator", "RainbowLoss"]

@@ -75,6 +75,8 @@ SYMBOLS = {
     "swg_heun_correct": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp]),
     "swg_mask_adjs": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
     "swg_sym_check": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
+    "swg_edm_objective": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "swg_edm_loss": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _f, _i32, _fp, _fp, _fp]),
     "swg_prof_enable": (C.c_int, [_i32]),
     "swg_prof_reset": (C.c_int, []),
     "swg_prof_kernels": (C.c_int, []),

@@ -772,6 +772,96 @@ __global__ __launch_bounds__(256) void k_sym_check(int N, const float* __restric
   if (threadIdx.x == 0 && err != 0.f) atomicAdd(acc, err);
 }
 
+// ------------------------------------------------------------------------------------------------
+// Training objective and loss of the EDM path (forward only): runner/objectives/edm.py:160-212,
+// loss/rainbow_loss.py:57-111.
+// ------------------------------------------------------------------------------------------------
+// sigma = exp(P_std r + P_mean), w = (sigma^2 + sd^2) / (sigma sd)^2 (:174-176); preconditioning scalars (:122-126)
+__global__ void k_edm_train_params(int B, const float* __restrict__ rnd, float* __restrict__ sigmas,
+                                   float* __restrict__ weights, float* __restrict__ c_skip, float* __restrict__ c_out,
+                                   float* __restrict__ c_in, float* __restrict__ c_noise) {
+  const int b = blockIdx.x * blockDim.x + threadIdx.x;
+  if (b >= B) return;
+  const float sd = 0.5f;
+  const float sg = expf(rnd[b] * 1.2f - 1.2f);
+  sigmas[b] = sg;
+  const float ss = sg * sd;
+  weights[b] = (sg * sg + sd * sd) / (ss * ss);
+  if (c_skip) c_skip[b] = sd * sd / (sg * sg + sd * sd);
+  if (c_out) c_out[b] = sg * sd / sqrtf(sg * sg + sd * sd);
+  if (c_in) c_in[b] = 1.0f / sqrtf(sd * sd + sg * sg);
+  if (c_noise) c_noise[b] = logf(sg) * 0.25f;
+}
+
+// noisy = mask(clean + sigma_b * sym(raw)), noise = mask(sigma_b * sym(raw))  (:181-186, graph_utils.py:122-152)
+__global__ __launch_bounds__(256) void k_edm_noisy(int N, const float* __restrict__ clean, const float* __restrict__ raw,
+                                                   const float* __restrict__ flags, const float* __restrict__ sigmas,
+                                                   float* __restrict__ noisy, float* __restrict__ noise) {
+  __shared__ float tR[32][33];
+  const int bi = blockIdx.z;
+  const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const size_t base = (size_t)bi * N * N;
+  const float sg = sigmas[bi];
+  for (int k = ty; k < 32; k += 8) {
+    const int rr = c0 + k, cc = r0 + tx;
+    tR[k][tx] = (rr < N && cc < N) ? raw[base + (size_t)rr * N + cc] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int r = r0 + k, c = c0 + tx;
+    if (r < N && c < N) {
+      const bool m = flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f;
+      float v = 0.f, e = 0.f;
+      if (m) {
+        e = sg * ((r < c) ? raw[base + (size_t)r * N + c] : ((r > c) ? tR[tx][k] : 0.f));
+        v = clean[base + (size_t)r * N + c] + e;
+      }
+      noisy[base + (size_t)r * N + c] = v;
+      if (noise) noise[base + (size_t)r * N + c] = e;
+    }
+  }
+}
+
+// per graph: S_b = w_b * sum_{ij} mask_ij (pred - target)^2 and n_b = sum flags_b (one workgroup per graph, fixed
+// summation order: deterministic)
+__global__ __launch_bounds__(256) void k_edm_loss_sums(int N, const float* __restrict__ pred,
+                                                       const float* __restrict__ target, const float* __restrict__ flags,
+                                                       const float* __restrict__ weights, float* __restrict__ S,
+                                                       float* __restrict__ nn) {
+  __shared__ float red[4];
+  const int bi = blockIdx.x;
+  const size_t base = (size_t)bi * N * N;
+  const float* fl = flags + (size_t)bi * N;
+  float acc = 0.f;
+  for (int r = threadIdx.x >> 6; r < N; r += 4) {
+    if (fl[r] == 0.f) continue;
+    for (int c = threadIdx.x & 63; c < N; c += 64) {
+      if (fl[c] == 0.f) continue;
+      const float d = pred[base + (size_t)r * N + c] - target[base + (size_t)r * N + c];
+      acc = fmaf(d, d, acc);
+    }
+  }
+  const float tot = block_sum_256(acc, red);
+  float cnt = 0.f;
+  for (int r = threadIdx.x; r < N; r += 256) cnt += fl[r];
+  __syncthreads();
+  const float n = block_sum_256(cnt, red);
+  if (threadIdx.x == 0) {
+    S[bi] = tot * (weights ? weights[bi] : 1.0f);
+    nn[bi] = n;
+  }
+}
+
+// reduction 'none': loss_b = S_b / n_b^2 * rlw ; reduction 'mean' (rainbow_loss.py:94-96): (sum_b S_b) / n_b^2 * rlw
+__global__ void k_edm_loss_finish(int B, const float* __restrict__ S, const float* __restrict__ nn, float rlw, int mean,
+                                  float* __restrict__ loss) {
+  float tot = 0.f;
+  if (mean)
+    for (int b = 0; b < B; ++b) tot += S[b];
+  for (int b = threadIdx.x; b < B; b += blockDim.x) loss[b] = (mean ? tot : S[b]) / (nn[b] * nn[b]) * rlw;
+}
+
 extern "C" {
 
 int swg_heun_churn(int32_t B, int32_t N, const float* x, const float* raw_noise, const float* node_flags,
@@ -824,6 +914,32 @@ int swg_sym_check(int32_t B, int32_t N, const float* a, float* acc, void* stream
   if (!a || !acc) return SWG_E_NULL;
   if (B <= 0 || N <= 0) return SWG_E_SHAPE;
   hipLaunchKernelGGL(k_sym_check, dim3(cdiv(N, 32), cdiv(N, 32), B), dim3(256), 0, (hipStream_t)stream, N, a, acc);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_edm_objective(int32_t B, int32_t N, const float* clean, const float* node_flags, const float* rnd_normal,
+                      const float* raw_noise, float* noisy, float* noise_added, float* sigmas, float* weights,
+                      float* c_skip, float* c_out, float* c_in, float* c_noise, void* stream) {
+  if (!clean || !node_flags || !rnd_normal || !raw_noise || !noisy || !sigmas || !weights) return SWG_E_NULL;
+  if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  hipLaunchKernelGGL(k_edm_train_params, dim3(cdiv(B, 64)), dim3(64), 0, (hipStream_t)stream, B, rnd_normal, sigmas,
+                     weights, c_skip, c_out, c_in, c_noise);
+  hipLaunchKernelGGL(k_edm_noisy, dim3(cdiv(N, 32), cdiv(N, 32), B), dim3(256), 0, (hipStream_t)stream, N, clean,
+                     raw_noise, node_flags, sigmas, noisy, noise_added);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, const float* node_flags,
+                 const float* weights, float regression_loss_weight, int32_t reduction_mean, float* loss,
+                 float* scratch2B, void* stream) {
+  if (!pred || !target || !node_flags || !loss || !scratch2B) return SWG_E_NULL;
+  if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  hipLaunchKernelGGL(k_edm_loss_sums, dim3(B), dim3(256), 0, (hipStream_t)stream, N, pred, target, node_flags, weights,
+                     scratch2B, scratch2B + B);
+  hipLaunchKernelGGL(k_edm_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, B, scratch2B, scratch2B + B,
+                     regression_loss_weight, reduction_mean, loss);
   SWG_LAUNCH_CHECK();
   return 0;
 }

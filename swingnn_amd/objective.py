@@ -1,0 +1,86 @@
+"""Drop-in forward halves of the EDM training objective and loss:
+``EDMObjectiveGenerator`` (runner/objectives/edm.py:132-212) and ``RainbowLoss`` (loss/rainbow_loss.py:38-111),
+same constructor keywords, method names, return tuples and quirks; the arithmetic runs in libswingnn_hip.so
+(swg_edm_objective / swg_edm_loss).  torch draws the random numbers (``torch.randn`` on the device in the reference's
+order: sigmas first, then the [B,N,N] noise) so seeds keep their meaning.  Forward only: the backward kernels of the
+train step (row a20) are not built yet, so the loss carries no autograd graph.
+"""
+import torch
+import torch.nn as nn
+
+from . import _lib as L
+from .engine import _as_f32, stream_ptr
+
+
+class EDMObjectiveGenerator:
+    """Training objective generator in adjacency space, 'edm' preconditioning and sigma distribution only."""
+
+    def __init__(self, precond, sigma_dist, *, other_params=None, dev=None, objective="edm"):
+        if precond != "edm" or sigma_dist != "edm":
+            raise NotImplementedError("swingnn_amd builds the shipped 'edm' preconditioning / sigma distribution only")
+        self.objective = objective
+        self.dev = dev
+        self.precond = precond
+        self.sigma_dist = sigma_dist
+        self.other_params = other_params
+
+    def _run(self, clean_adjs, node_flags):
+        clean = _as_f32(clean_adjs)
+        flags = _as_f32(node_flags)
+        if clean.device.type != "cuda":
+            raise RuntimeError("swingnn_amd runs on an MI355X only; there is no CPU fallback")
+        B, N = clean.shape[0], clean.shape[-1]
+        rnd = torch.randn(B, device=clean.device)             # edm.py:174
+        raw = torch.randn_like(clean)                         # graph_utils.py:115 (inside add_sym_normal_noise)
+        noisy, noise = torch.empty_like(clean), torch.empty_like(clean)
+        vec = torch.empty(6, B, device=clean.device, dtype=torch.float32)
+        L.check(L.lib.swg_edm_objective(B, N, clean.data_ptr(), flags.data_ptr(), rnd.data_ptr(), raw.data_ptr(),
+                                        noisy.data_ptr(), noise.data_ptr(), vec[0].data_ptr(), vec[1].data_ptr(),
+                                        vec[2].data_ptr(), vec[3].data_ptr(), vec[4].data_ptr(), vec[5].data_ptr(),
+                                        stream_ptr()), "swg_edm_objective")
+        sigmas, weights, c_skip, c_out, c_in, c_noise = vec.unbind(0)
+        return noisy, noise, sigmas, weights, (c_skip, c_out, c_in, c_noise)
+
+    def get_input_output(self, clean_adjs, node_flags, *args, **kwargs):
+        """-> net_input, net_cond, net_target, (c_skip, c_out, c_in, c_noise, sigmas, weights)   (edm.py:188-212)"""
+        noisy, _, sigmas, weights, (c_skip, c_out, c_in, c_noise) = self._run(clean_adjs, node_flags)
+        return noisy, sigmas, clean_adjs, (c_skip, c_out, c_in, c_noise, sigmas, weights)
+
+
+class RainbowLoss(nn.Module):
+    """Regression loss of the 'edm' / 'diffusion' objectives without re-weighting (rainbow_loss.py:57-111)."""
+
+    def __init__(self, regression_loss_weight, flag_reweight, objective):
+        super().__init__()
+        if flag_reweight or objective not in ("edm", "diffusion"):
+            raise NotImplementedError("swingnn_amd builds the shipped configuration: objective 'edm', no re-weighting")
+        self.regression_loss_weight = regression_loss_weight
+        self.flag_reweight = flag_reweight
+        self.objective = objective
+
+    def forward(self, net_pred, net_target, net_cond, adjs_perturbed, adjs_gt, node_flags, loss_weight=None,
+                cond_val=None, flag_matching=False, reduction='mean'):
+        if flag_matching:
+            raise NotImplementedError("graph matching of the target is a debug path of the reference")
+        return self.get_regression_loss(net_pred, net_target, net_cond, node_flags, None, loss_weight, cond_val,
+                                        reduction)
+
+    def get_regression_loss(self, predictions, targets, conditions, node_flags, reweight_coef, loss_weight,
+                            condition_true_values, reduction):
+        if reweight_coef is not None:
+            raise NotImplementedError("re-weighting is off in the shipped configuration")
+        if reduction not in ('mean', 'none', None):
+            raise NotImplementedError(reduction)
+        pred, tgt, flags = _as_f32(predictions), _as_f32(targets), _as_f32(node_flags)
+        assert len(flags.shape) == 2
+        if pred.device.type != "cuda":
+            raise RuntimeError("swingnn_amd runs on an MI355X only; there is no CPU fallback")
+        B, N = pred.shape[0], pred.shape[-1]
+        w = None if loss_weight is None else _as_f32(loss_weight)
+        loss = torch.empty(B, device=pred.device, dtype=torch.float32)
+        scratch = torch.empty(2 * B, device=pred.device, dtype=torch.float32)
+        L.check(L.lib.swg_edm_loss(B, N, pred.data_ptr(), tgt.data_ptr(), flags.data_ptr(),
+                                   None if w is None else w.data_ptr(), float(self.regression_loss_weight),
+                                   int(reduction == 'mean'), loss.data_ptr(), scratch.data_ptr(), stream_ptr()),
+                "swg_edm_loss")
+        return loss

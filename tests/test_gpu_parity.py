@@ -318,3 +318,54 @@ def test_edm_sampler(S, golden, golden_meta, name):
     sure = valid & (ref.abs() > 1e-2)
     assert float((thr == thr_ref)[sure].float().mean()) >= 0.999
     print(f"{name}: max err {err:.3g}, raw thresholded agreement {float((thr == thr_ref)[valid].float().mean()):.5f}")
+
+
+# ---------------------------------------------------------------------------------------------
+def test_objective_and_loss(S, golden):
+    """Rows a18/a19: training objective (noisy input, sigmas, weights, preconditioning scalars) and loss, forward."""
+    B, N = 6, 24
+    flags = filler.node_flags("flags", B, N, 5, 20, 3)
+    clean = filler.sym_adj("clean", B, N, flags, 3).sign()
+    # same draws as the golden generator (CPU generator), fed through the C-ABI directly
+    torch.manual_seed(5)
+    rnd = torch.randn(B)
+    raw = torch.randn_like(clean)
+    import ctypes as C
+    from swingnn_amd import _lib as L, engine as E
+    d = lambda t: t.to(DEV).contiguous()
+    cl, fl, rn, rw = d(clean), d(flags), d(rnd), d(raw)
+    noisy, noise = torch.empty_like(cl), torch.empty_like(cl)
+    vec = torch.empty(6, B, device=DEV)
+    L.check(L.lib.swg_edm_objective(B, N, cl.data_ptr(), fl.data_ptr(), rn.data_ptr(), rw.data_ptr(), noisy.data_ptr(),
+                                    noise.data_ptr(), *[vec[i].data_ptr() for i in range(6)], E.stream_ptr()), "obj")
+    sig, w = O.edm_training_sigmas_weights(rnd)
+    for got, want in ((vec[0], sig), (vec[1], w), (vec[0], golden["objective/sigmas"]), (vec[1], golden["objective/weights"])):
+        assert torch.allclose(got.cpu(), torch.as_tensor(want), rtol=2e-6, atol=1e-7)
+    c_skip, c_out, c_in, c_noise = O.edm_coefficients(sig)
+    for got, want in zip(vec[2:], (c_skip, c_out, c_in, c_noise)):
+        assert torch.allclose(got.cpu(), want.reshape(-1), rtol=3e-6, atol=1e-7)
+    want_noisy = O.edm_noisy_input(clean, flags, sig, raw)
+    assert torch.allclose(noisy.cpu(), want_noisy, rtol=2e-6, atol=1e-6)
+    assert torch.allclose(noisy.cpu(), torch.as_tensor(golden["objective/noisy"]), rtol=2e-6, atol=1e-6)
+    assert torch.allclose(noise.cpu(), want_noisy - O.mask_adjs(clean, flags), rtol=1e-5, atol=1e-6)
+    assert float(O.symmetry_residual(noisy.cpu())) == 0.0
+    # loss through the drop-in class, both reductions
+    pred = filler.sym_adj("pred", B, N, flags, 4)
+    lf = S.RainbowLoss(regression_loss_weight=1.0, flag_reweight=False, objective="edm")
+    none = lf(d(pred), cl, vec[0], noisy, cl, fl, loss_weight=vec[1], reduction='none')
+    want = O.edm_loss(pred, clean, flags, w)
+    assert torch.allclose(none.cpu(), want, rtol=1e-5)
+    assert torch.allclose(none.cpu(), torch.as_tensor(golden["objective/loss"]), rtol=1e-5)
+    mean = lf(d(pred), cl, vec[0], noisy, cl, fl, loss_weight=vec[1], reduction='mean')
+    n2 = flags.sum(-1) ** 2
+    assert torch.allclose(mean.cpu(), (want * n2).sum() / n2, rtol=1e-5)  # rainbow_loss.py:94-96 returns [B]
+    # the generator class: shapes, symmetry, masking, target passthrough, seeded reproducibility
+    gen = S.EDMObjectiveGenerator(precond="edm", sigma_dist="edm", other_params=None, dev=DEV)
+    torch.manual_seed(9)
+    a = gen.get_input_output(cl, fl)
+    torch.manual_seed(9)
+    b = gen.get_input_output(cl, fl)
+    assert a[2] is cl and a[0].shape == cl.shape and a[1].shape == (B,) and len(a[3]) == 6
+    assert torch.equal(a[0], b[0]) and torch.equal(a[1], b[1])
+    assert float(O.symmetry_residual(a[0].cpu())) == 0.0
+    assert torch.equal(O.mask_adjs(a[0].cpu(), flags), a[0].cpu())
