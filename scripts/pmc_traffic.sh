@@ -10,4 +10,4 @@ for C in FETCH_SIZE WRITE_SIZE; do
   rm -rf $R/gpurun_out/pmc_$C
   timeout -s KILL 300 rocprofv3 --pmc $C --output-format csv -d $R/gpurun_out/pmc_$C -o p -- python3 $R/scripts/prof_forward.py grid $B 2 > $R/gpurun_out/pmc_$C.log 2>&1
 done
-python3 $R/scripts/pmc_traffic_summary.py $R/gpurun_out $R/gpurun_out/pmc_traffic.json
+python3 $R/scripts/pmc_traffic_summary.py $R/gpurun_out $R/gpurun_out/pmc_traffic.json $B

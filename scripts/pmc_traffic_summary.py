@@ -1,7 +1,7 @@
 """Per-kernel HBM traffic from two rocprofv3 --pmc passes (FETCH_SIZE, WRITE_SIZE; see scripts/pmc_traffic.sh).
 hbm_bytes = (2 * FETCH_SIZE + WRITE_SIZE) * 1024: both counters are in KiB, and on gfx950 FETCH_SIZE tallies the
 128-byte requests of wide coalesced reads at 64 bytes (MI355X_MICROARCH.md, HBM), hence the factor 2 on the read side.
-usage: pmc_traffic_summary.py <dir with pmc_FETCH_SIZE/, pmc_WRITE_SIZE/> <out.json>"""
+usage: pmc_traffic_summary.py <dir with pmc_FETCH_SIZE/, pmc_WRITE_SIZE/> <out.json> [batch]"""
 import csv, glob, json, re, sys
 from collections import defaultdict
 
@@ -10,6 +10,7 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"([A-Za-z_0-9]+)(<[^>]*>)?", name)
     base = m.group(1)
+    base = {"k_patch_embed_mfma": "k_patch_embed", "k_final_readout_mfma": "k_final_readout"}.get(base, base)
     if base == "k_row" and m.group(2):
         mode = m.group(2).strip("<>").split(",")[-1].strip()
         base += "<" + {"0": "cond_ln", "1": "merge_ln", "2": "concat", "3": "ln_f32", "4": "breakup_ln"}.get(mode, mode) + ">"
@@ -29,6 +30,7 @@ def load(dirname, counter):
 
 
 d, out = sys.argv[1], sys.argv[2]
+batch = int(sys.argv[3]) if len(sys.argv) > 3 else 56
 f, nf = load(d, "FETCH_SIZE")
 w, nw = load(d, "WRITE_SIZE")
 res = {}
@@ -38,7 +40,7 @@ for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
     n = nf[k]
     res[k] = dict(launches=n, fetch_size_kib_per_launch=f[k] / n, write_size_kib_per_launch=w.get(k, 0.0) / max(nw.get(k, 1), 1),
                   hbm_bytes_per_launch=(2 * f[k] / n + w.get(k, 0.0) / max(nw.get(k, 1), 1)) * 1024)
-json.dump(dict(method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/prof_forward.py; "
+json.dump(dict(batch=batch, method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/prof_forward.py; "
                       "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 read-side correction)", kernels=res),
           open(out, "w"), indent=1)
 for k, v in res.items():

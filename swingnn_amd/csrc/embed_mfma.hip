@@ -339,7 +339,7 @@ int launch_breakup_post(const float* y, int B, int res, int Co, const float* g1,
   if (!breakup_post_supported(Co) || ldw % 8) return SWG_E_UNSUPPORTED;
   BreakupPostArgs a = {y, g1, b1, g2, b2, w, ldw, out, B * res * res, res};
   if (a.rows <= 0) return 0;
-  SwgProfScope ps(KID_ROW_BREAKUP_LN, 2.0 * 4.0 * a.rows * (double)Co * Co, 2.0 * 4.0 * a.rows * 4.0 * Co, s);
+  SwgProfScope ps(KID_BREAKUP_POST, 2.0 * 4.0 * a.rows * (double)Co * Co, 2.0 * 4.0 * a.rows * 4.0 * Co, s);
   hipLaunchKernelGGL((k_breakup_post<96>), dim3(persistent_grid((a.rows + 15) / 16)), dim3(256), 0, s, a);
   SWG_LAUNCH_CHECK();
   return 0;

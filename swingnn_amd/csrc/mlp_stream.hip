@@ -285,7 +285,7 @@ int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img,
   if (!mlp_stream_supported(C)) return SWG_E_UNSUPPORTED;
   if (T <= 0) return 0;
   MlpArgs a = {x, out, img, b1, b2, g, b, T};
-  SwgProfScope ps(KID_FUSED_MLP, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
+  SwgProfScope ps(KID_MLP_STREAM, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
   int rc = (C == 384) ? launch_one<384, 32, 3>(a, s) : launch_one<192, 64, 3>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();

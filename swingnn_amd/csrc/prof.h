@@ -21,6 +21,10 @@ enum SwgKernelId {
   KID_HEUN,
   KID_FUSED_WATTN,
   KID_FUSED_MLP,
+  KID_MLP_STREAM,
+  KID_WATTN_RING,
+  KID_WATTN_RES,
+  KID_BREAKUP_POST,
   KID_COUNT
 };
 

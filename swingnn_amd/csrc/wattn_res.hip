@@ -396,7 +396,7 @@ int launch_wattn_res(const swg_block* blk, int B, const float* x, const float* c
   const int total = B * nW;
   const int nwg = min(cdiv(total, NW), 256);
   const double T = (double)B * blk->res * blk->res;
-  SwgProfScope ps(KID_FUSED_WATTN, 8.0 * T * C * C + 4.0 * T * 36 * C, 8.0 * T * C + 8.0 * C * C, s);
+  SwgProfScope ps(KID_WATTN_RES, 8.0 * T * C * C + 4.0 * T * 36 * C, 8.0 * T * C + 8.0 * C * C, s);
   static bool attr_set = false;
   if (!attr_set) {
     hipError_t e = hipFuncSetAttribute((const void*)k_wattn_res<C, NW, AHEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,

@@ -511,7 +511,7 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   const int nwg = cdiv(B * nW, 4);
   const double T = (double)B * blk->res * blk->res;
   const double gemm = wattn_ring_fuses_proj(C) ? 8.0 : 6.0;
-  SwgProfScope ps(KID_FUSED_WATTN, gemm * T * C * C + 4.0 * T * 36 * C, (gemm == 8.0 ? 8.0 : 6.0) * T * C + gemm * C * C, s);
+  SwgProfScope ps(KID_WATTN_RING, gemm * T * C * C + 4.0 * T * 36 * C, (gemm == 8.0 ? 8.0 : 6.0) * T * C + gemm * C * C, s);
   int r;
   if (C == 192) r = launch_t<192, true, 4, 1, 5, true>(a, nwg, s);
   else r = launch_t<384, false, 5, 1, 5, true>(a, nwg, s);
