@@ -32,9 +32,9 @@ for res, Cd, heads in stages:
         if which in ('both', 'attn'):
             us = timeit(lambda: L.check(L.lib.swg_wattn_fwd(C.byref(d), B, x.data_ptr(), cond.data_ptr(), 2 * Cd, out.data_ptr(), ws.data_ptr(), ws.numel(), E.stream_ptr()), 'attn'))
             n = 36
+            print(f"C={Cd:4d} res={res:3d} T={T:7d} attn  shift={shift}     {us:8.1f} us  {(8*T*Cd*Cd+4*T*n*Cd)/us/1e6:7.1f} TF/s  {8*T*Cd/us/1e3:7.1f} GB/s(min)")
             if len(sys.argv) > 3:
                 from swingnn_amd import prof
                 with prof.profiled():
                     for _ in range(5): L.check(L.lib.swg_wattn_fwd(C.byref(d), B, x.data_ptr(), cond.data_ptr(), 2 * Cd, out.data_ptr(), ws.data_ptr(), ws.numel(), E.stream_ptr()), 'attn')
                 print("   ", {k: round(v['ms'] / 5 * 1e3, 1) for k, v in prof.read().items()})
-            print(f"C={Cd:4d} res={res:3d} T={T:7d} attn  shift={shift}     {us:8.1f} us  {(8*T*Cd*Cd+4*T*n*Cd)/us/1e6:7.1f} TF/s  {8*T*Cd/us/1e3:7.1f} GB/s(min)")
