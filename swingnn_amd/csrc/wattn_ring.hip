@@ -126,6 +126,16 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   // The weight ring is primed only after the row loads: LDS-DMA issued ahead of them would delay them (loads
   // return in order).
   bf16x8 xa[NTM][KS];
+  // Projection accumulators.  With in-kernel conditioning (!PRE_LN) they START as shortcut + proj bias: accumulator
+  // row 4*lg+r of out tile nt = 2*ks+hh is channel 32ks + 8lg + 4hh + r (rho order of the image rows), the channels
+  // this lane conditions for k-step ks, so the epilogue is a plain store.
+  f32x4 acc[FUSE_PROJ ? NT : 1][NTM];
+  if (FUSE_PROJ && PRE_LN) {
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+      for (int mt = 0; mt < NTM; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
   const float* crow = a.cond + (size_t)b * a.cond_stride + a.cond_off;
   if (PRE_LN) {
 #pragma unroll
@@ -160,11 +170,19 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
         const float xv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
         const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
         const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
+        float pb[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+        if (FUSE_PROJ) {
+          const float4 pb0 = *reinterpret_cast<const float4*>(a.proj_b + c0);
+          const float4 pb1 = *reinterpret_cast<const float4*>(a.proj_b + c0 + 4);
+          pb[0] = pb0.x; pb[1] = pb0.y; pb[2] = pb0.z; pb[3] = pb0.w;
+          pb[4] = pb1.x; pb[5] = pb1.y; pb[6] = pb1.z; pb[7] = pb1.w;
+        }
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
           const float v = silu_f(sh[j] + xv[j] * (sc[j] + 1.f));
           x1[ks][j] = v;
           s += v;
+          if (FUSE_PROJ) acc[FUSE_PROJ ? 2 * ks + (j >> 2) : 0][mt][j & 3] = v + pb[j];
         }
       }
       s = rows_sum(s);
@@ -213,14 +231,6 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       krel[mt][r] = 4 * (jy * W2 + jx);
       rids[mt] |= jr << (4 + 4 * r);
     }
-  }
-
-  f32x4 acc[FUSE_PROJ ? NT : 1][NTM];
-  if (FUSE_PROJ) {
-#pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-      for (int mt = 0; mt < NTM; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
   }
 
   // unit 0 has landed everywhere (and the tables are visible): start the fragment ring
@@ -447,7 +457,18 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 #undef STAGE_PIECE
   wait_vmcnt<0>();  // trailing refills have landed before the workgroup's LDS is released
 
-  if (FUSE_PROJ) {
+  if (FUSE_PROJ && !PRE_LN) {
+    // ---- epilogue: scatter back to token order (shortcut and bias are already in the accumulators) ----
+#pragma unroll
+    for (int mt = 0; mt < NTM; ++mt) {
+      if (!live || mt * 16 + l15 >= NTOK) continue;
+      float* orow = a.out + (size_t)tokq[mt] * C;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt)
+        *reinterpret_cast<f32x4*>(orow + 32 * (nt >> 1) + 8 * lg + 4 * (nt & 1)) = acc[FUSE_PROJ ? nt : 0][mt];
+    }
+  }
+  if (FUSE_PROJ && PRE_LN) {
     // ---- epilogue: + proj bias + shortcut x1 (recomputed from the cached row), scatter back to token order.
     // Accumulator row 4*lg+r of tile nt = 2*ks+hh is channel 32ks+8lg+4hh+r (rho order of the image rows).
 #pragma unroll
@@ -494,7 +515,7 @@ bool wattn_ring_supported(int C, int heads, int win, int res) {
 }
 bool wattn_ring_fuses_proj(int C) { return C != 384; }
 
-bool wattn_ring_wants_xn(int C) { return true; }
+bool wattn_ring_wants_xn(int C) { return true; }  // in-kernel LN (PRE_LN = false) measured slower at C = 192
 
 // FUSE_PROJ geometries write x_out (`out`); C = 384 writes o (bf16 [T, ldo]) for the projection GEMM.  C >= 192 take
 // the rows already conditioned + normalised (xn, bf16 [T, ldxn], from k_row<cond_ln>): in-kernel LayerNorm of a
