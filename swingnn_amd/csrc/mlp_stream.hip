@@ -42,8 +42,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int C, int HC, int NBUF>
-__global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
+template <int C, int HC, int NBUF, int LB>
+__global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
   constexpr int KS = C / 32;        // k-steps of fc1
   constexpr int NT = C / 16;        // output feature tiles of fc2
   constexpr int HT = HC / 16;       // hidden tiles per chunk (fc1 output tiles)
@@ -262,23 +262,23 @@ __global__ __launch_bounds__(256, 1) void k_mlp_stream(MlpArgs a) {
   }
 }
 
-template <int C, int HC, int NBUF>
+template <int C, int HC, int NBUF, int LB>
 int launch_one(const MlpArgs& a, hipStream_t s) {
-  constexpr size_t lds = (size_t)NBUF * (4 * HC * C) + (size_t)(4 * C + HC) * sizeof(float);
+  constexpr size_t lds = (size_t)NBUF * (4 * HC * C) + (size_t)(4 * C + 2 * HC) * sizeof(float);
   static bool attr_set = false;  // dynamic LDS above 64 KiB needs an explicit opt-in
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_stream<C, HC, NBUF>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_stream<C, HC, NBUF, LB>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_mlp_stream<C, HC, NBUF>), dim3(cdiv(a.T, 128)), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((k_mlp_stream<C, HC, NBUF, LB>), dim3(cdiv(a.T, 128)), dim3(256), lds, s, a);
   return 0;
 }
 
 }  // namespace
 
-bool mlp_stream_supported(int C) { return C == 384 || C == 192; }
+bool mlp_stream_supported(int C) { return C == 384 || C == 192 || C == 96; }
 
 int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                       const float* g, const float* b, hipStream_t s) {
@@ -286,7 +286,7 @@ int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img,
   if (T <= 0) return 0;
   MlpArgs a = {x, out, img, b1, b2, g, b, T};
   SwgProfScope ps(KID_MLP_STREAM, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
-  int rc = (C == 384) ? launch_one<384, 32, 3>(a, s) : launch_one<192, 64, 3>(a, s);
+  int rc = (C == 384) ? launch_one<384, 32, 3, 1>(a, s) : launch_one<192, 64, 3, 1>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();
   return 0;
