@@ -197,6 +197,79 @@ int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, c
                  float* scratch2B, void* stream);
 
 
+/* ---- training step: backward passes of the op-level entry points ------------------------ *
+ * The reference has no explicit backward code: `loss.backward()` (runner/trainer/trainer.py:135) differentiates the
+ * module forwards cited above with autograd.  Each *_bwd entry point below is the derivative of the *_fwd entry point
+ * of the same name: it RECOMPUTES the op's intermediates from the saved op input (nothing but op inputs is kept
+ * between forward and backward), runs the Linear-layer gradients on the bf16 MFMA GEMM (dX = dY W, dW = dY^T X with a
+ * split reduction) and everything else in fp32 row kernels.  Parameter gradients are ACCUMULATED (+=) into the
+ * caller's fp32 buffers (the layout of the nn.Parameter); activation gradients are written.  Scratch comes from
+ * (ws, ws_bytes) >= swg_train_workspace_bytes().  Gradients carry bf16 operand rounding (relative 2^-9 per product
+ * term, fp32 accumulation), the usual mixed-precision training contract. */
+typedef struct swg_lin_train {
+  const void* wt; /* bf16 [K, Np]: the weight TRANSPOSED, N zero-padded to Np = ceil32(N) (derived cache)   */
+  float* dw;      /* fp32 [N, K] gradient accumulator                                                      */
+  float* db;      /* fp32 [N] or NULL                                                                      */
+} swg_lin_train;
+typedef struct swg_ln_train {
+  float* dg; /* [dim] */
+  float* db; /* [dim] */
+} swg_ln_train;
+typedef struct swg_block_train {
+  swg_ln_train ln1, ln2;
+  swg_lin_train qkv, proj, fc1, fc2;
+  float* drpb; /* [(2win-1)^2, heads] */
+} swg_block_train;
+typedef struct swg_merge_train {
+  swg_ln_train ln;
+  swg_lin_train red;
+} swg_merge_train;
+typedef struct swg_breakup_train {
+  swg_lin_train pre;
+  swg_ln_train ln, post_ln;
+  swg_lin_train post;
+} swg_breakup_train;
+typedef struct swg_ends_train {
+  const void* pe_wb; /* bf16 [C0, ceil32(in_ch p p)]: conv weight as a padded GEMM operand                  */
+  float* dpe_w;      /* [C0, in_ch p p]                                                                     */
+  float* dpe_b;      /* [C0]                                                                                */
+  swg_ln_train pe_ln, norm;
+  const void* ro_wb; /* bf16 [C0, ceil32(p p)]: the collapsed read-out map as a padded GEMM operand         */
+  float* dro_w;      /* [C0, p p] gradient of the collapsed map (the caller chains it to read_out.{0,1,2})  */
+  float* dro_b;      /* [32]: column sums of the pixel gradients; sum of the first p p = d(collapsed bias)  */
+} swg_ends_train;
+
+size_t swg_train_workspace_bytes(const swg_net* net, int32_t B);
+/* (c_skip, c_out, c_in, c_noise) rows of runner/objectives/edm.py:122-126 for `labels` = sigmas (mode 1) or
+ * (0, 1, 1, label) (mode 0): coef [B,4], c_noise [B]. */
+int swg_edm_coef(int32_t B, const float* labels, int32_t labels_uniform, int32_t mode, float* coef, float* c_noise,
+                 void* stream);
+/* d swg_wattn_fwd: dy [B,L,C] -> dx [B,L,C]; dcond rows (stride dcond_stride) get the block's (dscale | dshift). */
+int swg_wattn_bwd(const swg_block* blk, const swg_block_train* tr, int32_t B, const float* x_in, const float* cond,
+                  int32_t cond_stride, const float* dy, float* dx, float* dcond, int32_t dcond_stride, void* ws,
+                  size_t ws_bytes, void* stream);
+/* d swg_ln_mlp_fwd */
+int swg_ln_mlp_bwd(const swg_block* blk, const swg_block_train* tr, int32_t B, const float* x_in, const float* dy,
+                   float* dx, void* ws, size_t ws_bytes, void* stream);
+/* d swg_patch_merge_fwd: dy [B, res*res/4, 2C] -> dx [B, res*res, C] */
+int swg_patch_merge_bwd(const swg_merge* m, const swg_merge_train* tr, int32_t B, const float* x_in, const float* dy,
+                        float* dx, void* ws, size_t ws_bytes, void* stream);
+/* d swg_patch_expand_fwd: dy [B, 4*res*res, Cin/4] -> dx, dskip [B, res*res, Cin/2] */
+int swg_patch_expand_bwd(const swg_breakup* u, const swg_breakup_train* tr, int32_t B, const float* x, const float* skip,
+                         const float* dy, float* dx, float* dskip, void* ws, size_t ws_bytes, void* stream);
+/* d swg_patch_embed_fwd w.r.t. its parameters and the conditioning row (the adjacency input is data) */
+int swg_patch_embed_bwd(const swg_net* net, const swg_ends_train* tr, int32_t B, const float* x, const float* self_cond,
+                        const float* c_in, int32_t c_in_stride, const float* cond, int32_t cond_stride, const float* dtok,
+                        float* dcond, int32_t dcond_stride, void* ws, size_t ws_bytes, void* stream);
+/* d swg_readout_sym_precond_fwd: dD [B,N,N] -> dtok [B,L,C0] (+ final LayerNorm and collapsed read-out gradients) */
+int swg_readout_sym_precond_bwd(const swg_net* net, const swg_ends_train* tr, int32_t B, const float* tok,
+                                const float* node_flags, const float* coef, const float* dD, float* dtok, void* ws,
+                                size_t ws_bytes, void* stream);
+/* d swg_edm_loss (reduction 'none', the trainer's call :120-129): grad_loss [B] -> grad_pred [B,N,N] */
+int swg_edm_loss_bwd(int32_t B, int32_t N, const float* pred, const float* target, const float* node_flags,
+                     const float* weights, const float* grad_loss, float regression_loss_weight, float* grad_pred,
+                     void* stream);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------------------- *
  * When enabled, every internal kernel launch is bracketed by HIP events on its stream and its
  * algorithmic FLOPs / bytes are tallied per kernel.  swg_prof_read synchronises the recorded events.

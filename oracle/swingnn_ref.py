@@ -274,7 +274,8 @@ def precond_forward(sd, cfg, x, node_flags, sigmas, coin: bool):
                                     for i, t in enumerate(edm_coefficients(sigmas)))
     sc = None
     if cfg["self_condition"] and coin:
-        sc = mask_adjs(c_skip * x + c_out * swingnn_forward(net, cfg, c_in * x, node_flags, c_noise, None), node_flags)
+        with torch.no_grad():  # :41-45 (no_grad + detach_): the self-conditioning pass carries no gradient
+            sc = mask_adjs(c_skip * x + c_out * swingnn_forward(net, cfg, c_in * x, node_flags, c_noise, None), node_flags)
     Fx = swingnn_forward(net, cfg, c_in * x, node_flags, c_noise, sc)
     return mask_adjs(c_skip * x + c_out * Fx, node_flags)
 

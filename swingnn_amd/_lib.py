@@ -56,6 +56,32 @@ class SwgNet(C.Structure):
                 ("norm", SwgLn), ("ro_w", _fp), ("ro_b", C.c_float)]
 
 
+class SwgLinTrain(C.Structure):
+    _fields_ = [("wt", _fp), ("dw", _fp), ("db", _fp)]
+
+
+class SwgLnTrain(C.Structure):
+    _fields_ = [("dg", _fp), ("db", _fp)]
+
+
+class SwgBlockTrain(C.Structure):
+    _fields_ = [("ln1", SwgLnTrain), ("ln2", SwgLnTrain), ("qkv", SwgLinTrain), ("proj", SwgLinTrain),
+                ("fc1", SwgLinTrain), ("fc2", SwgLinTrain), ("drpb", _fp)]
+
+
+class SwgMergeTrain(C.Structure):
+    _fields_ = [("ln", SwgLnTrain), ("red", SwgLinTrain)]
+
+
+class SwgBreakupTrain(C.Structure):
+    _fields_ = [("pre", SwgLinTrain), ("ln", SwgLnTrain), ("post_ln", SwgLnTrain), ("post", SwgLinTrain)]
+
+
+class SwgEndsTrain(C.Structure):
+    _fields_ = [("pe_wb", _fp), ("dpe_w", _fp), ("dpe_b", _fp), ("pe_ln", SwgLnTrain), ("norm", SwgLnTrain),
+                ("ro_wb", _fp), ("dro_w", _fp), ("dro_b", _fp)]
+
+
 # every symbol include/swingnn_hip.h declares: name -> (restype, argtypes)
 _i32, _sz, _f = C.c_int32, C.c_size_t, C.c_float
 SYMBOLS = {
@@ -77,6 +103,19 @@ SYMBOLS = {
     "swg_sym_check": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
     "swg_edm_objective": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "swg_edm_loss": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _f, _i32, _fp, _fp, _fp]),
+    "swg_train_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),
+    "swg_edm_coef": (C.c_int, [_i32, _fp, _i32, _i32, _fp, _fp, _fp]),
+    "swg_wattn_bwd": (C.c_int, [C.POINTER(SwgBlock), C.POINTER(SwgBlockTrain), _i32, _fp, _fp, _i32, _fp, _fp, _fp, _i32,
+                                _fp, _sz, _fp]),
+    "swg_ln_mlp_bwd": (C.c_int, [C.POINTER(SwgBlock), C.POINTER(SwgBlockTrain), _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_patch_merge_bwd": (C.c_int, [C.POINTER(SwgMerge), C.POINTER(SwgMergeTrain), _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_patch_expand_bwd": (C.c_int, [C.POINTER(SwgBreakup), C.POINTER(SwgBreakupTrain), _i32, _fp, _fp, _fp, _fp, _fp,
+                                       _fp, _sz, _fp]),
+    "swg_patch_embed_bwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgEndsTrain), _i32, _fp, _fp, _fp, _i32, _fp, _i32,
+                                      _fp, _fp, _i32, _fp, _sz, _fp]),
+    "swg_readout_sym_precond_bwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgEndsTrain), _i32, _fp, _fp, _fp, _fp, _fp,
+                                              _fp, _sz, _fp]),
+    "swg_edm_loss_bwd": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _fp, _fp]),
     "swg_prof_enable": (C.c_int, [_i32]),
     "swg_prof_reset": (C.c_int, []),
     "swg_prof_kernels": (C.c_int, []),

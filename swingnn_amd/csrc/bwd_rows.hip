@@ -1,0 +1,459 @@
+// Memory-bound kernels of the training backward pass: LayerNorm / GELU / conditioning
+// derivatives, the 2x2 patch permutation of PatchMerging / PatchBreakup, bf16 casts and transposes that feed the
+// MFMA GEMMs (dX = dY W, dW = dY^T X), column sums for the bias gradients, and the embedding / read-out / loss
+// ends of the chain.  Activations and gradients on the residual stream are fp32; bf16 exists only as GEMM operands.
+// Parameter gradients are ACCUMULATED (+=) into fp32 buffers with vector atomics (float add order is not fixed).
+#include "common.h"
+
+namespace {
+
+constexpr float kInvSqrt2 = 0.70710678118654752440f;
+constexpr float kInvSqrt2Pi = 0.39894228040143267794f;
+
+__device__ __forceinline__ float gelu_exact(float x) { return 0.5f * x * (1.0f + erff(x * kInvSqrt2)); }
+__device__ __forceinline__ float gelu_grad(float x) {
+  return 0.5f * (1.0f + erff(x * kInvSqrt2)) + x * kInvSqrt2Pi * __expf(-0.5f * x * x);
+}
+
+// ---- fp32 [rows, C] (row stride ldx) -> bf16 [rows, ldo], columns [C, ldo) zero ----
+__global__ __launch_bounds__(256) void k_cast_pad(const float* __restrict__ x, int rows, int C, int ldx,
+                                                  bf16* __restrict__ out, int ldo) {
+  const int nst = ldo >> 2;
+  const size_t total = (size_t)rows * nst;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int r = (int)(i / nst), c = (int)(i - (size_t)r * nst) * 4;
+    float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+    if (c < C) v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+    *reinterpret_cast<uint2*>(out + (size_t)r * ldo + c) = pack_bf16x4(v.x, v.y, v.z, v.w);
+  }
+}
+
+// ---- src [M, ld] (N columns used) -> dst bf16 [N, ldd] = src^T, columns [M, ldd) zero ----
+template <typename T>
+__global__ __launch_bounds__(256) void k_transpose_bf16(const T* __restrict__ src, int M, int N, int ld,
+                                                        bf16* __restrict__ dst, int ldd) {
+  __shared__ float tile[32][33];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
+  const int m0 = blockIdx.x * 32, n0 = blockIdx.y * 32;
+  for (int k = ty; k < 32; k += 8) {
+    const int m = m0 + k, n = n0 + tx;
+    tile[k][tx] = (m < M && n < N) ? (float)src[(size_t)m * ld + n] : 0.f;
+  }
+  __syncthreads();
+  for (int k = ty; k < 32; k += 8) {
+    const int n = n0 + k, m = m0 + tx;
+    if (n < N && m < ldd) dst[(size_t)n * ldd + m] = (bf16)tile[tx][k];
+  }
+}
+
+// ---- out[n] += sum_m src[m][n] ----
+template <typename T>
+__global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ src, int M, int N, int ld, int rpb,
+                                                float* __restrict__ out) {
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= N) return;
+  const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
+  float s = 0.f;
+  for (int m = r0; m < r1; ++m) s += (float)src[(size_t)m * ld + n];
+  atomicAdd(out + n, s);
+}
+
+// ---- GELU (exact erf form, swin_gnn.py:10,15) on the bf16 hidden buffer, forward and derivative ----
+__global__ __launch_bounds__(256) void k_gelu_fwd(const bf16* __restrict__ h, bf16* __restrict__ a, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(h + 8 * i);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)gelu_exact((float)v[j]);
+    *reinterpret_cast<bf16x8*>(a + 8 * i) = o;
+  }
+}
+__global__ __launch_bounds__(256) void k_gelu_bwd(const bf16* __restrict__ h, const bf16* __restrict__ da,
+                                                  bf16* __restrict__ dh, size_t n8) {
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < n8; i += (size_t)gridDim.x * 256) {
+    const bf16x8 v = *reinterpret_cast<const bf16x8*>(h + 8 * i);
+    const bf16x8 g = *reinterpret_cast<const bf16x8*>(da + 8 * i);
+    bf16x8 o;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) o[j] = (bf16)((float)g[j] * gelu_grad((float)v[j]));
+    *reinterpret_cast<bf16x8*>(dh + 8 * i) = o;
+  }
+}
+
+// ---- LayerNorm backward: one wavefront per row (grid-stride), V float4 chunks per lane ----
+//   xhat = (x - mean) rstd, dxhat = dy g, dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) [+ dres]
+//   dg += sum_rows dy xhat, db += sum_rows dy
+template <int V>
+__global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ dy,
+                                                const float* __restrict__ g, const float* __restrict__ dres, int rows,
+                                                int C, float* __restrict__ dx, float* __restrict__ dg,
+                                                float* __restrict__ db) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int nch = C >> 2;
+  float4 ag[V], ab[V], gg[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+    const int c = lane + 64 * i;
+    gg[i] = (c < nch) ? *reinterpret_cast<const float4*>(g + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
+  }
+  const float invC = 1.0f / (float)C;
+  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+    float4 xv[V], dv[V];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + 64 * i;
+      xv[i] = dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < nch) {
+        xv[i] = *reinterpret_cast<const float4*>(x + (size_t)row * C + 4 * c);
+        dv[i] = *reinterpret_cast<const float4*>(dy + (size_t)row * C + 4 * c);
+      }
+      s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
+    }
+    const float mean = group_sum<64>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+      if (lane + 64 * i < nch) {
+        xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
+        q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
+      }
+    const float rstd = ln_rstd(group_sum<64>(q) * invC);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      xv[i].x *= rstd; xv[i].y *= rstd; xv[i].z *= rstd; xv[i].w *= rstd;  // xhat
+      ag[i].x += dv[i].x * xv[i].x; ag[i].y += dv[i].y * xv[i].y; ag[i].z += dv[i].z * xv[i].z; ag[i].w += dv[i].w * xv[i].w;
+      ab[i].x += dv[i].x; ab[i].y += dv[i].y; ab[i].z += dv[i].z; ab[i].w += dv[i].w;
+      dv[i].x *= gg[i].x; dv[i].y *= gg[i].y; dv[i].z *= gg[i].z; dv[i].w *= gg[i].w;  // dxhat
+      s1 += (dv[i].x + dv[i].y) + (dv[i].z + dv[i].w);
+      s2 += (dv[i].x * xv[i].x + dv[i].y * xv[i].y) + (dv[i].z * xv[i].z + dv[i].w * xv[i].w);
+    }
+    const float m1 = group_sum<64>(s1) * invC, m2 = group_sum<64>(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + 64 * i;
+      if (c < nch) {
+        float4 o;
+        o.x = rstd * (dv[i].x - m1 - xv[i].x * m2); o.y = rstd * (dv[i].y - m1 - xv[i].y * m2);
+        o.z = rstd * (dv[i].z - m1 - xv[i].z * m2); o.w = rstd * (dv[i].w - m1 - xv[i].w * m2);
+        if (dres) {
+          const float4 r = *reinterpret_cast<const float4*>(dres + (size_t)row * C + 4 * c);
+          o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
+        }
+        *reinterpret_cast<float4*>(dx + (size_t)row * C + 4 * c) = o;
+      }
+    }
+  }
+  // fold the four waves' column partials through LDS, then one atomic per column per workgroup
+  for (int w = 0; w < 4; ++w) {
+    if (wave == w) {
+#pragma unroll
+      for (int i = 0; i < V; ++i) {
+        const int c = lane + 64 * i;
+        if (c < nch) {
+          float4* pg = reinterpret_cast<float4*>(red + 4 * c);
+          float4* pb = reinterpret_cast<float4*>(red + C + 4 * c);
+          if (w == 0) { *pg = ag[i]; *pb = ab[i]; }
+          else {
+            float4 a = *pg, b = *pb;
+            a.x += ag[i].x; a.y += ag[i].y; a.z += ag[i].z; a.w += ag[i].w;
+            b.x += ab[i].x; b.y += ab[i].y; b.z += ab[i].z; b.w += ab[i].w;
+            *pg = a; *pb = b;
+          }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dg + c, red[c]);
+    atomicAdd(db + c, red[C + c]);
+  }
+}
+
+// ---- conditioning backward: xc = silu(z), z = shift + x (1 + scale)  (swin_gnn.py:238-240, :571-574) ----
+// dx = dxc silu'(z) (1 + scale); dscale[b,c] += sum_t dz x; dshift[b,c] += sum_t dz.  grid (B, token chunks).
+__global__ __launch_bounds__(256) void k_cond_bwd(const float* __restrict__ x, const float* __restrict__ dxc,
+                                                  const float* __restrict__ cond, int cond_stride, int cond_off, int C,
+                                                  int L, int tpb, float* __restrict__ dx, float* __restrict__ dcond,
+                                                  int dcond_stride) {
+  const int b = blockIdx.x;
+  const int t0 = blockIdx.y * tpb, t1 = min(L, t0 + tpb);
+  const float* crow = cond + (size_t)b * cond_stride + cond_off;
+  float* drow = dcond + (size_t)b * dcond_stride + cond_off;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    const float sc = crow[c] + 1.f, sh = crow[C + c];
+    float asc = 0.f, ash = 0.f;
+    for (int t = t0; t < t1; ++t) {
+      const size_t o = ((size_t)b * L + t) * C + c;
+      const float xv = x[o];
+      const float z = sh + xv * sc;
+      const float sg = 1.0f / (1.0f + __expf(-z));
+      const float dz = dxc[o] * sg * (1.0f + z * (1.0f - sg));
+      if (dx) dx[o] = dz * sc;
+      asc += dz * xv;
+      ash += dz;
+    }
+    atomicAdd(drow + c, asc);
+    atomicAdd(drow + C + c, ash);
+  }
+}
+
+// ---- 2x2 patch permutation shared by PatchMerging (gather, swin_gnn.py:325-330) and PatchBreakup (scatter, :389-397):
+// packed [B, (res/2)^2, 4 C] <-> tokens [B, res^2, C]; chunk k of a packed row is token (2Y + (k&1), 2X + (k>>1)).
+// dir 0: packed <- tokens, dir 1: tokens <- packed.  res = side of the TOKEN grid. ----
+__global__ __launch_bounds__(256) void k_perm22(const float* __restrict__ src, float* __restrict__ dst, int B, int res,
+                                                int C, int dir) {
+  const int r2 = res >> 1, cs = C >> 2;
+  const size_t total = (size_t)B * r2 * r2 * 4 * cs;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int cc = (int)(i % cs);
+    size_t r = i / cs;
+    const int k = (int)(r & 3);
+    r >>= 2;
+    const int X = (int)(r % r2);
+    r /= r2;
+    const int Y = (int)(r % r2);
+    const int b = (int)(r / r2);
+    const size_t tok = (size_t)b * res * res + (size_t)(2 * Y + (k & 1)) * res + (2 * X + (k >> 1));
+    const size_t po = i * 4, to = tok * C + 4 * cc;
+    if (dir == 0) *reinterpret_cast<float4*>(dst + po) = *reinterpret_cast<const float4*>(src + to);
+    else *reinterpret_cast<float4*>(dst + to) = *reinterpret_cast<const float4*>(src + po);
+  }
+}
+
+// ---- PatchEmbed input taps as a GEMM operand: bf16 [T, Kp], column k = (channel, i, j) of the conv weight
+// (swin_gnn.py:566, channel order cat([self_cond, x]) :769-771, x scaled by c_in precond.py:47) ----
+__global__ __launch_bounds__(256) void k_embed_im2col(const float* __restrict__ x, const float* __restrict__ sc,
+                                                      const float* __restrict__ c_in, int c_in_stride, int B, int N, int p,
+                                                      int in_ch, int self_cond, bf16* __restrict__ out, int Kp) {
+  const int hp = N / p, L = hp * hp, pp = p * p, kin = in_ch * pp;
+  const size_t total = (size_t)B * L * Kp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const size_t row = i / Kp;
+    float v = 0.f;
+    if (k < kin) {
+      const int bi = (int)(row / L), rem = (int)(row - (size_t)bi * L);
+      const int Y = rem / hp, X = rem - Y * hp;
+      const int ci = k / pp, ij = k - ci * pp;
+      const int ii = ij / p, jj = ij - ii * p;
+      const size_t off = ((size_t)bi * N + (Y * p + ii)) * N + (X * p + jj);
+      const bool is_x = (!self_cond) || ci == in_ch - 1;
+      if (is_x) v = (c_in ? c_in[(size_t)bi * c_in_stride] : 1.0f) * x[off];
+      else if (sc) v = sc[off];
+    }
+    out[i] = (bf16)v;
+  }
+}
+
+// ---- read-out end of the chain (swin_gnn.py:773-778, precond.py:49-51): D = mask(c_skip x + c_out sym(mask(R))) with
+// R[b, Yp+i, Xp+j] = tokn[t] . A[:, ip+j] + bias.  dR = 0.5 c_out mask (dD + dD^T) as a bf16 [T, Kp] GEMM operand. ----
+__global__ __launch_bounds__(256) void k_readout_dpix(const float* __restrict__ dD, const float* __restrict__ flags,
+                                                      const float* __restrict__ coef, int B, int N, int p,
+                                                      bf16* __restrict__ out, int Kp) {
+  const int hp = N / p, L = hp * hp, pp = p * p;
+  const size_t total = (size_t)B * L * Kp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const size_t row = i / Kp;
+    float v = 0.f;
+    if (k < pp) {
+      const int bi = (int)(row / L), rem = (int)(row - (size_t)bi * L);
+      const int Y = rem / hp, X = rem - Y * hp;
+      const int ii = k / p, jj = k - ii * p;
+      const int r = Y * p + ii, c = X * p + jj;
+      if (flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f) {
+        const size_t base = (size_t)bi * N * N;
+        const float c_out = coef ? coef[4 * bi + 1] : 1.f;
+        v = 0.5f * c_out * (dD[base + (size_t)r * N + c] + dD[base + (size_t)c * N + r]);
+      }
+    }
+    out[i] = (bf16)v;
+  }
+}
+
+// ---- grad[N, K] += tmp[N, ldt][:, :K] (weight gradients whose K is not a multiple of 4) ----
+__global__ __launch_bounds__(256) void k_add_slice(const float* __restrict__ tmp, int N, int K, int ldt,
+                                                   float* __restrict__ grad) {
+  const int total = N * K;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < total; i += gridDim.x * 256) {
+    const int n = i / K, k = i - n * K;
+    grad[i] += tmp[(size_t)n * ldt + k];
+  }
+}
+
+// ---- loss/rainbow_loss.py:84-111 backward, reduction 'none': loss_b = rlw w_b sum mask (p - t)^2 / nf_b^2
+// dpred = gloss_b rlw w_b 2 mask (p - t) / nf_b^2 ----
+__global__ __launch_bounds__(256) void k_edm_loss_bwd(int N, const float* __restrict__ pred, const float* __restrict__ tgt,
+                                                      const float* __restrict__ flags, const float* __restrict__ weights,
+                                                      const float* __restrict__ gloss, float rlw,
+                                                      float* __restrict__ dpred) {
+  __shared__ float red[4];
+  const int b = blockIdx.y;
+  float nf = 0.f;
+  for (int i = threadIdx.x; i < N; i += 256) nf += flags[(size_t)b * N + i];
+  nf = group_sum<64>(nf);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = nf;
+  __syncthreads();
+  nf = red[0] + red[1] + red[2] + red[3];
+  const float k = 2.0f * gloss[b] * rlw * (weights ? weights[b] : 1.0f) / (nf * nf);
+  const size_t base = (size_t)b * N * N;
+  for (int i = blockIdx.x * 256 + threadIdx.x; i < N * N; i += gridDim.x * 256) {
+    const int r = i / N, c = i - r * N;
+    const bool m = flags[(size_t)b * N + r] != 0.f && flags[(size_t)b * N + c] != 0.f;
+    dpred[base + i] = m ? k * (pred[base + i] - tgt[base + i]) : 0.f;
+  }
+}
+
+inline unsigned gs_grid(size_t items) { return (unsigned)max((size_t)1, min((size_t)4096, (items + 255) / 256)); }
+
+}  // namespace
+
+int launch_cast_pad(const float* x, int rows, int C, int ldx, bf16* out, int ldo, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (C % 4 || ldo % 4 || ldx % 4 || ldo < C) return SWG_E_SHAPE;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)rows * (4.0 * C + 2.0 * ldo), s);
+  hipLaunchKernelGGL(k_cast_pad, dim3(gs_grid((size_t)rows * (ldo / 4))), dim3(256), 0, s, x, rows, C, ldx, out, ldo);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_transpose_f32(const float* src, int M, int N, int ld, bf16* dst, int ldd, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  if (ldd < M) return SWG_E_SHAPE;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)M * N * 6.0, s);
+  hipLaunchKernelGGL((k_transpose_bf16<float>), dim3(cdiv(ldd, 32), cdiv(N, 32)), dim3(256), 0, s, src, M, N, ld, dst, ldd);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+int launch_transpose_bf16(const bf16* src, int M, int N, int ld, bf16* dst, int ldd, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  if (ldd < M) return SWG_E_SHAPE;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)M * N * 4.0, s);
+  hipLaunchKernelGGL((k_transpose_bf16<bf16>), dim3(cdiv(ldd, 32), cdiv(N, 32)), dim3(256), 0, s, src, M, N, ld, dst, ldd);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline int colsum_rpb(int M) { return max(64, cdiv(M, 256)); }
+int launch_colsum_f32(const float* src, int M, int N, int ld, float* out, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  const int rpb = colsum_rpb(M);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)M * N * 4.0, s);
+  hipLaunchKernelGGL((k_colsum<float>), dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, s, src, M, N, ld, rpb, out);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+int launch_colsum_bf16(const bf16* src, int M, int N, int ld, float* out, hipStream_t s) {
+  if (M <= 0 || N <= 0) return 0;
+  const int rpb = colsum_rpb(M);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)M * N * 2.0, s);
+  hipLaunchKernelGGL((k_colsum<bf16>), dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, s, src, M, N, ld, rpb, out);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gelu_fwd(const bf16* h, bf16* a, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  if (n % 8) return SWG_E_SHAPE;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, 4.0 * (double)n, s);
+  hipLaunchKernelGGL(k_gelu_fwd, dim3(gs_grid(n / 8)), dim3(256), 0, s, h, a, n / 8);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+int launch_gelu_bwd(const bf16* h, const bf16* da, bf16* dh, size_t n, hipStream_t s) {
+  if (n == 0) return 0;
+  if (n % 8) return SWG_E_SHAPE;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, 6.0 * (double)n, s);
+  hipLaunchKernelGGL(k_gelu_bwd, dim3(gs_grid(n / 8)), dim3(256), 0, s, h, da, dh, n / 8);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
+                  float* dg, float* db, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (C % 4 || C > 3072) return SWG_E_UNSUPPORTED;
+  if (!x || !dy || !g || !dx || !dg || !db) return SWG_E_NULL;
+  const int V = cdiv(C / 4, 64);
+  const int grid = min(cdiv(rows, 4), 1024);
+  const size_t lds = (size_t)2 * C * sizeof(float);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)rows * C * (dres ? 16.0 : 12.0), s);
+#define LNB(VV) hipLaunchKernelGGL((k_ln_bwd<VV>), dim3(grid), dim3(256), lds, s, x, dy, g, dres, rows, C, dx, dg, db)
+  if (V <= 1) LNB(1);
+  else if (V == 2) LNB(2);
+  else if (V == 3) LNB(3);
+  else if (V == 4) LNB(4);
+  else if (V <= 6) LNB(6);
+  else if (V <= 8) LNB(8);
+  else LNB(12);
+#undef LNB
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int cond_stride, int cond_off, int B, int L, int C,
+                    float* dx, float* dcond, int dcond_stride, hipStream_t s) {
+  if (B <= 0 || L <= 0) return 0;
+  if (!x || !dxc || !cond || !dcond) return SWG_E_NULL;
+  const int chunks = max(1, min(L, cdiv(2048, B)));  // ~2048 workgroups
+  const int tpb = cdiv(L, chunks);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)B * L * C * 12.0, s);
+  hipLaunchKernelGGL(k_cond_bwd, dim3(B, cdiv(L, tpb)), dim3(256), 0, s, x, dxc, cond, cond_stride, cond_off, C, L, tpb, dx,
+                     dcond, dcond_stride);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_perm22(const float* src, float* dst, int B, int res, int C, int dir, hipStream_t s) {
+  if (B <= 0) return 0;
+  if (res % 2 || C % 4) return SWG_E_SHAPE;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)B * res * res * C * 8.0, s);
+  hipLaunchKernelGGL(k_perm22, dim3(gs_grid((size_t)B * res * res * (C / 4))), dim3(256), 0, s, src, dst, B, res, C, dir);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_embed_im2col(const swg_net* net, int B, const float* x, const float* sc, const float* c_in, int c_in_stride,
+                        bf16* out, int Kp, hipStream_t s) {
+  const int hp = net->N / net->p;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)B * net->N * net->N * 8.0, s);
+  hipLaunchKernelGGL(k_embed_im2col, dim3(gs_grid((size_t)B * hp * hp * Kp)), dim3(256), 0, s, x, sc, c_in, c_in_stride, B,
+                     net->N, net->p, net->in_ch, net->self_cond, out, Kp);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_readout_dpix(const float* dD, const float* flags, const float* coef, int B, int N, int p, bf16* out, int Kp,
+                        hipStream_t s) {
+  const int hp = N / p;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)B * N * N * 8.0, s);
+  hipLaunchKernelGGL(k_readout_dpix, dim3(gs_grid((size_t)B * hp * hp * Kp)), dim3(256), 0, s, dD, flags, coef, B, N, p, out,
+                     Kp);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_add_slice(const float* tmp, int N, int K, int ldt, float* grad, hipStream_t s) {
+  if (N <= 0 || K <= 0) return 0;
+  hipLaunchKernelGGL(k_add_slice, dim3(gs_grid((size_t)N * K)), dim3(256), 0, s, tmp, N, K, ldt, grad);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+extern "C" int swg_edm_loss_bwd(int32_t B, int32_t N, const float* pred, const float* target, const float* node_flags,
+                                const float* weights, const float* grad_loss, float regression_loss_weight,
+                                float* grad_pred, void* stream) {
+  if (!pred || !target || !node_flags || !grad_loss || !grad_pred) return SWG_E_NULL;
+  if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)B * N * N * 12.0, s);
+  hipLaunchKernelGGL(k_edm_loss_bwd, dim3(min(cdiv(N * N, 256), 64), B), dim3(256), 0, s, N, pred, target, node_flags,
+                     weights, grad_loss, regression_loss_weight, grad_pred);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}

@@ -162,6 +162,31 @@ struct GemmEpi {
   int n_store;
 };
 int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, const GemmEpi& e, hipStream_t s);
+// weight-gradient form: out[M,N] (dense fp32) += A[M,Kp] @ W[N,Kp]^T, reduction split over the grid into `partial`
+size_t gemm_splitk_ws_floats(int M, int N);
+int launch_gemm_splitk(const bf16* A, int lda, const bf16* W, int ldw, int M, int N, int Kp, float* out, float* partial,
+                       size_t partial_floats, hipStream_t s);
+// bwd_rows.hip : memory-bound kernels of the backward pass
+int launch_cast_pad(const float* x, int rows, int C, int ldx, bf16* out, int ldo, hipStream_t s);
+int launch_transpose_f32(const float* src, int M, int N, int ld, bf16* dst, int ldd, hipStream_t s);
+int launch_transpose_bf16(const bf16* src, int M, int N, int ld, bf16* dst, int ldd, hipStream_t s);
+int launch_colsum_f32(const float* src, int M, int N, int ld, float* out, hipStream_t s);
+int launch_colsum_bf16(const bf16* src, int M, int N, int ld, float* out, hipStream_t s);
+int launch_gelu_fwd(const bf16* h, bf16* a, size_t n, hipStream_t s);
+int launch_gelu_bwd(const bf16* h, const bf16* da, bf16* dh, size_t n, hipStream_t s);
+int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
+                  float* dg, float* db, hipStream_t s);
+int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int cond_stride, int cond_off, int B, int L, int C,
+                    float* dx, float* dcond, int dcond_stride, hipStream_t s);
+int launch_perm22(const float* src, float* dst, int B, int res, int C, int dir, hipStream_t s);
+int launch_embed_im2col(const swg_net* net, int B, const float* x, const float* sc, const float* c_in, int c_in_stride,
+                        bf16* out, int Kp, hipStream_t s);
+int launch_readout_dpix(const float* dD, const float* flags, const float* coef, int B, int N, int p, bf16* out, int Kp,
+                        hipStream_t s);
+int launch_add_slice(const float* tmp, int N, int K, int ldt, float* grad, hipStream_t s);
+// wattn_bwd.hip : backward of the window attention core
+int launch_wattn_bwd(const bf16* qkv, int ldq, const bf16* dO, int ldo, int B, int res, int win, int shift, int heads,
+                     int C, const float* rpb, bf16* dqkv, int lddq, float* drpb, hipStream_t s);
 // wattn.hip : window attention core on a qkv buffer
 int launch_wattn_core(const bf16* qkv, int ldq, int B, int res, int win, int shift, int heads, int C, const float* rpb,
                       bf16* o, int ldo, hipStream_t s);

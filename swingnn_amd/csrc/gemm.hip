@@ -36,8 +36,9 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 template <int BK>
-__global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W,
-                                                 int M, int N, int Kp, GemmEpi e, int tiles_n) {
+__global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
+                                                 int M, int N, int Kp, GemmEpi e, int tiles_n, int kslice,
+                                                 size_t out_slice) {
   constexpr int CH = Swz<BK>::CH;
   constexpr int LD_PER_THR = (BM * CH) / 256;  // 16-byte chunks per thread per operand tile
   constexpr int KSTEPS = BK / 32;
@@ -45,6 +46,13 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
   __shared__ __attribute__((aligned(16))) bf16 sW[2][BN * BK];
 
   const int nwg = gridDim.x;
+  if (kslice > 0) {  // split-K (weight gradients): slice blockIdx.y of the reduction, own partial output
+    const int z = blockIdx.y;
+    A += (size_t)z * kslice;
+    W += (size_t)z * kslice;
+    Kp = min(kslice, Kp - z * kslice);
+    e.out_f32 += (size_t)z * out_slice;
+  }
   const int tile = xcd_remap(blockIdx.x, nwg);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;  // n fastest: neighbours share the X panel
   const int m0 = tm * BM, n0 = tn * BN;
@@ -64,7 +72,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
     const int id = tid + i * 256;
     const int row = id / CH, ch = id - row * CH;
     gx[i] = A + (size_t)min(m0 + row, M - 1) * lda + ch * 8;
-    gw[i] = W + (size_t)min(n0 + row, N - 1) * Kp + ch * 8;
+    gw[i] = W + (size_t)min(n0 + row, N - 1) * ldw + ch * 8;
     soff[i] = row * BK + Swz<BK>::chunk(row, ch) * 8;
   }
 #define G_LOAD(KT)                                                             \
@@ -161,7 +169,58 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
   }
 }
 
+// out[i] += sum_s partial[s][i]
+__global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int S, size_t n4, size_t slice,
+                                                       float* __restrict__ out) {
+  for (size_t i = blockIdx.x * 256 + threadIdx.x; i < n4; i += (size_t)gridDim.x * 256) {
+    float4 a = *reinterpret_cast<const float4*>(out + 4 * i);
+    for (int z = 0; z < S; ++z) {
+      const float4 p = *reinterpret_cast<const float4*>(partial + (size_t)z * slice + 4 * i);
+      a.x += p.x; a.y += p.y; a.z += p.z; a.w += p.w;
+    }
+    *reinterpret_cast<float4*>(out + 4 * i) = a;
+  }
+}
+
 }  // namespace
+
+// Weight-gradient form: out[M,N] += A[M,Kp] @ W[N,Kp]^T with a LONG reduction (Kp = tokens) and a small output, so the
+// reduction is split over blockIdx.y into fp32 partials that a second kernel folds into `out` (deterministic order).
+// A row stride lda, W row stride ldw (both >= Kp, multiples of 8); out dense [M, N].
+size_t gemm_splitk_ws_floats(int M, int N) {
+  const int tiles = cdiv(M, BM) * cdiv(N, BN);
+  return (size_t)(512 + tiles) * BM * BN;
+}
+int launch_gemm_splitk(const bf16* A, int lda, const bf16* W, int ldw, int M, int N, int Kp, float* out, float* partial,
+                       size_t partial_floats, hipStream_t s) {
+  if (M <= 0 || N <= 0 || Kp <= 0) return 0;
+  if (Kp % 32 || lda % 8 || ldw % 8 || lda < Kp || ldw < Kp || N % 4) return SWG_E_SHAPE;
+  if (!A || !W || !out) return SWG_E_NULL;
+  const int tiles_m = cdiv(M, BM), tiles_n = cdiv(N, BN);
+  const int tiles = tiles_m * tiles_n;
+  int S = min(min(cdiv(512, tiles), max(Kp / 256, 1)), 64);
+  int kslice = round_up(cdiv(Kp, S), 32);
+  S = cdiv(Kp, kslice);
+  GemmEpi e = {};
+  e.ldo = N; e.n_store = N;
+  SwgProfScope ps(KID_GEMM, 2.0 * M * (double)N * Kp, 2.0 * M * Kp + 2.0 * N * (double)Kp + 8.0 * M * (double)N, s);
+  if (S <= 1) {
+    e.out_f32 = out; e.residual = out; e.ldr = N;
+    hipLaunchKernelGGL(k_gemm_nt<32>, dim3(tiles), dim3(256), 0, s, A, lda, W, ldw, M, N, Kp, e, tiles_n, 0, (size_t)0);
+    SWG_LAUNCH_CHECK();
+    return 0;
+  }
+  const size_t slice = (size_t)M * N;
+  if (!partial || partial_floats < slice * S) return SWG_E_WORKSPACE;
+  e.out_f32 = partial;
+  hipLaunchKernelGGL(k_gemm_nt<32>, dim3(tiles, S), dim3(256), 0, s, A, lda, W, ldw, M, N, Kp, e, tiles_n, kslice, slice);
+  SWG_LAUNCH_CHECK();
+  const size_t n4 = slice / 4;
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)min((size_t)1024, (n4 + 255) / 256)), dim3(256), 0, s, partial, S, n4,
+                     slice, out);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, const GemmEpi& e, hipStream_t s) {
   if (M <= 0) return 0;
@@ -179,9 +238,9 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   // residency hides the short-K prologue / epilogue better than the longer k-step amortises its barrier (measured
   // per shape, scripts/bench_gemm.py: +5..25 % for M >= 32k, -3..10 % for M = 8k)
   if (Kp % 64 == 0 && M < 16384)
-    hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
+    hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n, 0, (size_t)0);
   else
-    hipLaunchKernelGGL(k_gemm_nt<32>, dim3(nwg), dim3(256), 0, s, A, lda, W, M, N, Kp, ee, tiles_n);
+    hipLaunchKernelGGL(k_gemm_nt<32>, dim3(nwg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n, 0, (size_t)0);
   SWG_LAUNCH_CHECK();
   return 0;
 }

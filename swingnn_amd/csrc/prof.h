@@ -25,6 +25,9 @@ enum SwgKernelId {
   KID_WATTN_RING,
   KID_WATTN_RES,
   KID_BREAKUP_POST,
+  KID_BWD_ROWS,
+  KID_WATTN_BWD,
+  KID_OPTIM,
   KID_COUNT
 };
 

@@ -27,7 +27,8 @@ const char* kNames[KID_COUNT] = {"k_gemm_nt",      "k_wattn_core",  "k_row<cond_
                                  "k_row<concat>",  "k_row<ln_f32>", "k_row<breakup_ln>", "k_gemv_rows",
                                  "k_pos_embed",    "k_edm_coef",    "k_patch_embed",  "k_final_readout",
                                  "k_sym_precond",  "k_heun",        "k_wattn_fused",  "k_mlp_fused",
-                                 "k_mlp_stream",   "k_wattn_ring",  "k_wattn_res",    "k_breakup_post"};
+                                 "k_mlp_stream",   "k_wattn_ring",  "k_wattn_res",    "k_breakup_post",
+                                 "bwd_rows",       "k_wattn_bwd",   "k_adam_ema"};
 
 void drain() {  // caller holds the lock; synchronises the recorded events
   for (size_t i = 0; i < P.used; ++i) {

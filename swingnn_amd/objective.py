@@ -2,8 +2,8 @@
 ``EDMObjectiveGenerator`` (runner/objectives/edm.py:132-212) and ``RainbowLoss`` (loss/rainbow_loss.py:38-111),
 same constructor keywords, method names, return tuples and quirks; the arithmetic runs in libswingnn_hip.so
 (swg_edm_objective / swg_edm_loss).  torch draws the random numbers (``torch.randn`` on the device in the reference's
-order: sigmas first, then the [B,N,N] noise) so seeds keep their meaning.  Forward only: the backward kernels of the
-train step (row a20) are not built yet, so the loss carries no autograd graph.
+order: sigmas first, then the [B,N,N] noise) so seeds keep their meaning.  The loss is differentiable w.r.t. the
+prediction (reduction 'none', the trainer's call) through swg_edm_loss_bwd.
 """
 import torch
 import torch.nn as nn
@@ -47,6 +47,33 @@ class EDMObjectiveGenerator:
         return noisy, sigmas, clean_adjs, (c_skip, c_out, c_in, c_noise, sigmas, weights)
 
 
+class _EdmLossFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, pred, tgt, flags, w, rlw, mean):
+        B, N = pred.shape[0], pred.shape[-1]
+        loss = torch.empty(B, device=pred.device, dtype=torch.float32)
+        scratch = torch.empty(2 * B, device=pred.device, dtype=torch.float32)
+        L.check(L.lib.swg_edm_loss(B, N, pred.data_ptr(), tgt.data_ptr(), flags.data_ptr(),
+                                   None if w is None else w.data_ptr(), float(rlw), int(mean), loss.data_ptr(),
+                                   scratch.data_ptr(), stream_ptr()), "swg_edm_loss")
+        ctx.save_for_backward(pred, tgt, flags, w)
+        ctx.rlw, ctx.mean = float(rlw), mean
+        return loss
+
+    @staticmethod
+    def backward(ctx, gloss):
+        if ctx.mean:
+            raise NotImplementedError("swingnn_amd: backward of reduction='mean' (the trainer uses 'none' + .mean())")
+        pred, tgt, flags, w = ctx.saved_tensors
+        B, N = pred.shape[0], pred.shape[-1]
+        gloss = _as_f32(gloss)
+        dpred = torch.empty_like(pred)
+        L.check(L.lib.swg_edm_loss_bwd(B, N, pred.data_ptr(), tgt.data_ptr(), flags.data_ptr(),
+                                       None if w is None else w.data_ptr(), gloss.data_ptr(), ctx.rlw,
+                                       dpred.data_ptr(), stream_ptr()), "swg_edm_loss_bwd")
+        return dpred, None, None, None, None, None
+
+
 class RainbowLoss(nn.Module):
     """Regression loss of the 'edm' / 'diffusion' objectives without re-weighting (rainbow_loss.py:57-111)."""
 
@@ -77,10 +104,4 @@ class RainbowLoss(nn.Module):
             raise RuntimeError("swingnn_amd runs on an MI355X only; there is no CPU fallback")
         B, N = pred.shape[0], pred.shape[-1]
         w = None if loss_weight is None else _as_f32(loss_weight)
-        loss = torch.empty(B, device=pred.device, dtype=torch.float32)
-        scratch = torch.empty(2 * B, device=pred.device, dtype=torch.float32)
-        L.check(L.lib.swg_edm_loss(B, N, pred.data_ptr(), tgt.data_ptr(), flags.data_ptr(),
-                                   None if w is None else w.data_ptr(), float(self.regression_loss_weight),
-                                   int(reduction == 'mean'), loss.data_ptr(), scratch.data_ptr(), stream_ptr()),
-                "swg_edm_loss")
-        return loss
+        return _EdmLossFn.apply(pred, tgt.reshape(pred.shape), flags, w, self.regression_loss_weight, reduction == 'mean')

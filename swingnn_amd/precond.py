@@ -35,8 +35,7 @@ class Precond(nn.Module):
         return self._sym_acc
 
     def forward(self, x, node_flags, sigmas, self_cond=None, *args, **model_kwargs):
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters()):
-            raise NotImplementedError("swingnn_amd: backward kernels are not built yet; run under torch.no_grad()")
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in self.model.parameters())
         sigmas = torch.as_tensor(sigmas, device=x.device).reshape(-1)
         uniform = sigmas.numel() == 1 or (sigmas.dim() == 1 and sigmas.stride(0) == 0)  # sampler: .expand(B), edm.py:180
         if not uniform and sigmas.numel() != x.shape[0]:
@@ -47,8 +46,13 @@ class Precond(nn.Module):
         if self.self_condition and np.random.rand() < 0.5:
             sc = E.network_pass(cache, 1, x, node_flags, labels, uniform, None)
         acc = None if self.symmetry_check == 'off' else self._acc(x.device)
-        D = E.network_pass(cache, 1, x, node_flags, labels, uniform, sc if self.model.self_condition else None,
-                           sym_err=acc)
+        if with_grad:  # training step (runner/trainer/trainer.py:110): forward that keeps op inputs + HIP backward
+            from .train import denoise_with_grad
+            D = denoise_with_grad(self.model, 1, x, node_flags, sigmas.expand(x.shape[0]) if uniform else sigmas,
+                                  sc if self.model.self_condition else None, acc)
+        else:
+            D = E.network_pass(cache, 1, x, node_flags, labels, uniform, sc if self.model.self_condition else None,
+                               sym_err=acc)
         if self.symmetry_check == 'eager':
             self.assert_symmetric()
         return D

@@ -24,7 +24,8 @@ def _pair(v):
 
 def _no_grad_path(*tensors):
     if torch.is_grad_enabled() and any(t is not None and t.requires_grad for t in tensors):
-        raise NotImplementedError("swingnn_amd: backward kernels are not built yet; run under torch.no_grad()")
+        raise NotImplementedError("swingnn_amd: sub-module forwards are inference-only; gradients flow through "
+                                  "SwinGNN.forward / Precond.forward (swingnn_amd/train.py)")
 
 
 def _run(fn, what, *args):
@@ -332,7 +333,6 @@ class SwinGNN(nn.Module):
 
     def forward(self, x, node_flags, noise_labels, self_cond=None):
         """x [B,N,N] (or [B,1,N,N]), node_flags [B,N], noise_labels [B], self_cond [B,N,N] | None -> [B,N,N]."""
-        _no_grad_path(x, self_cond, self.norm.weight)
         if x.dim() == 4:
             x = x.squeeze(1)
         if self_cond is not None and self_cond.dim() == 4:
@@ -343,4 +343,7 @@ class SwinGNN(nn.Module):
         labels = noise_labels.reshape(-1)
         if labels.numel() == 1 and x.shape[0] != 1:
             labels = labels.expand(x.shape[0])
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .train import denoise_with_grad
+            return denoise_with_grad(self, 0, x, node_flags, labels, self_cond)
         return E.network_pass(cache, 0, x, node_flags, labels, False, self_cond)

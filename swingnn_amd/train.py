@@ -1,0 +1,315 @@
+"""Training path of the drop-in denoiser: forward that keeps op inputs, backward through the
+``swg_*_bwd`` entry points of libswingnn_hip.so, wrapped in one ``torch.autograd.Function`` over the whole
+``Precond(SwinGNN)`` / ``SwinGNN`` call so that ``loss.backward()`` (runner/trainer/trainer.py:135) fills ``.grad``
+of the ordinary nn.Parameters (Adam, EMA, DDP and ``clip_grad_norm_`` see nothing unusual).
+
+What is kept between forward and backward: the input of every op (block input, block mid-point, merge / breakup
+inputs, final tokens) in fp32 -- each backward op recomputes its own intermediates.  Every token- or pixel-sized
+tensor is produced by HIP kernels.  Two parameter-sized chains run as torch ops on the device because they are
+smaller than a kernel launch is worth: the [B, 512] noise-embedding MLP + affine layers (reference :757-760, :195,
+:554; its input gradient ``dcond`` comes from the kernels) and the chain rule through the read-out collapse
+(three convolutions with no non-linearity, engine.collapse_read_out).  The gradient of a skip tensor used twice
+(encoder successor + decoder concat, :743) is summed with one ``add_`` as autograd itself would.
+"""
+import ctypes as C
+
+import torch
+import torch.nn.functional as F
+
+from . import _lib as L
+from . import engine as E
+
+
+def _kp(k):
+    return (k + 31) // 32 * 32
+
+
+def _wt(weight):
+    """bf16 [K, Np]: transposed weight, N zero-padded to a multiple of 32 (operand of dX = dY W)."""
+    w = weight.detach()
+    N, K = w.shape
+    out = torch.zeros((K, _kp(N)), dtype=torch.bfloat16, device=w.device)
+    out[:, :N] = w.t()
+    return out
+
+
+def _padded_bf16(w2d):
+    N, K = w2d.shape
+    out = torch.zeros((N, _kp(K)), dtype=torch.bfloat16, device=w2d.device)
+    out[:, :K] = w2d
+    return out
+
+
+class TrainCache:
+    """Derived operands of the backward pass (transposed bf16 weights), built once per parameter version."""
+
+    def __init__(self, model, cache: E.NetCache):
+        self.model = model
+        self.wt = {}
+        for name, p in model.named_parameters():
+            if p.dim() == 2 and name.endswith("weight") and ".affine." not in name and "map_layer" not in name:
+                self.wt[name] = _wt(p)
+        pe = model.patch_embed
+        self.pe_wb = _padded_bf16(pe.proj.weight.detach().reshape(model.embed_dim, -1))
+        ro_w, _ = E.collapse_read_out(model.read_out, pe.patch_size[0])
+        self.ro_wb = _padded_bf16(ro_w)
+        self._ws = {}
+
+    def ws_bytes(self, cache, B):
+        n = self._ws.get(B)
+        if n is None:
+            n = int(L.lib.swg_train_workspace_bytes(C.byref(cache.net), B))
+            if n == 0:
+                raise L.SwgError("swg_train_workspace_bytes: unsupported network geometry")
+            self._ws[B] = n
+        return n
+
+
+def get_train_cache(model, cache):
+    if getattr(model, "_swg_train_key", None) is not cache:
+        model._swg_train_cache = TrainCache(model, cache)
+        model._swg_train_key = cache
+    return model._swg_train_cache
+
+
+class GradBook:
+    """One zero-filled fp32 buffer holding the gradient of every kernel-side parameter, 256-byte aligned views."""
+
+    def __init__(self, model, device):
+        self.views = {}
+        off = 0
+        spans = []
+        for name, p in model.named_parameters():
+            spans.append((name, off, p.shape))
+            off += (p.numel() + 63) // 64 * 64
+        self.flat = torch.zeros(off + 64, dtype=torch.float32, device=device)
+        for name, o, shape in spans:
+            n = 1
+            for d in shape:
+                n *= d
+            self.views[name] = self.flat[o:o + n].view(shape)
+
+    def ptr(self, name):
+        return self.views[name].data_ptr()
+
+
+def _lin_train(tc, book, prefix, bias=True):
+    return L.SwgLinTrain(tc.wt[prefix + ".weight"].data_ptr(), book.ptr(prefix + ".weight"),
+                         book.ptr(prefix + ".bias") if bias else None)
+
+
+def _ln_train(book, prefix):
+    return L.SwgLnTrain(book.ptr(prefix + ".weight"), book.ptr(prefix + ".bias"))
+
+
+def _layer_names(model):
+    S = model.num_layers
+    return [f"down_layers.{i}" for i in range(S)] + [f"up_layers.{i}" for i in range(S)]
+
+
+def _run(fn, what, *args):
+    L.check(fn(*args), what)
+
+
+def _c(ptr_struct):
+    return C.byref(ptr_struct)
+
+
+def forward_keep(model, mode, x, node_flags, labels, self_cond, sym_err=None):
+    """SwinGNN / Precond-core forward through the op-level entry points; returns (D, saved state for backward)."""
+    cache = E.get_cache(model)
+    tc = get_train_cache(model, cache)
+    net = cache.net
+    x = E._as_f32(x)
+    flags = E._as_f32(node_flags)
+    labels = E._as_f32(labels.reshape(-1))
+    sc = None if self_cond is None else E._as_f32(self_cond)
+    B, N = x.shape[0], x.shape[-1]
+    if x.dim() != 3 or x.shape[1] != N or N != net.N:
+        raise AssertionError(f"Input image size ({x.shape[-2]}*{N}) doesn't match model ({net.N}*{net.N}).")
+    if labels.numel() != B:
+        raise AssertionError("one noise label per sample is required in training")
+    dev = x.device
+    st = E.stream_ptr()
+    ws = E.workspace(dev, max(cache.ws_bytes(B), tc.ws_bytes(cache, B)))
+    wp, wn = ws.data_ptr(), ws.numel()
+    f32 = dict(dtype=torch.float32, device=dev)
+    coef = torch.empty((B, 4), **f32)
+    cnoise = torch.empty((B,), **f32)
+    _run(L.lib.swg_edm_coef, "swg_edm_coef", B, labels.data_ptr(), 0, mode, coef.data_ptr(), cnoise.data_ptr(), st)
+    ct = net.cond_total
+    cond = torch.empty((B, ct), **f32)
+    _run(L.lib.swg_noise_embed, "swg_noise_embed", _c(net), B, cnoise.data_ptr(), cond.data_ptr(), wp, wn, st)
+    hp = N // net.p
+    tok = torch.empty((B, hp * hp, net.C0), **f32)
+    _run(L.lib.swg_patch_embed_fwd, "swg_patch_embed_fwd", _c(net), B, x.data_ptr(), E._ptr(sc), coef.data_ptr() + 8, 4,
+         cond.data_ptr(), ct, tok.data_ptr(), st)
+    saved, skips = [], {}
+    cur = tok
+    for li in range(net.n_layers):
+        ly = cache.layers[li]
+        if ly.up:
+            up = ly.up.contents
+            si = net.n_layers - 1 - li
+            skip = skips[si]
+            out = torch.empty((B, 4 * up.res * up.res, up.Cin // 4), **f32)
+            _run(L.lib.swg_patch_expand_fwd, "swg_patch_expand_fwd", ly.up, B, cur.data_ptr(), skip.data_ptr(),
+                 out.data_ptr(), wp, wn, st)
+            saved.append(("up", li, si, cur, skip))
+            cur = out
+        for j in range(ly.n_blocks):
+            blk = C.byref(ly.blocks[j])
+            mid = torch.empty_like(cur)
+            _run(L.lib.swg_wattn_fwd, "swg_wattn_fwd", blk, B, cur.data_ptr(), cond.data_ptr(), ct, mid.data_ptr(), wp, wn, st)
+            out = torch.empty_like(cur)
+            _run(L.lib.swg_ln_mlp_fwd, "swg_ln_mlp_fwd", blk, B, mid.data_ptr(), out.data_ptr(), wp, wn, st)
+            saved.append(("blk", li, j, cur, mid))
+            cur = out
+        if ly.down:
+            dn = ly.down.contents
+            out = torch.empty((B, (dn.res // 2) ** 2, 2 * dn.C), **f32)
+            _run(L.lib.swg_patch_merge_fwd, "swg_patch_merge_fwd", ly.down, B, cur.data_ptr(), out.data_ptr(), wp, wn, st)
+            saved.append(("down", li, cur))
+            skips[li] = out
+            cur = out
+    D = torch.empty_like(x)
+    _run(L.lib.swg_readout_sym_precond_fwd, "swg_readout_sym_precond_fwd", _c(net), B, cur.data_ptr(), x.data_ptr(),
+         flags.data_ptr(), coef.data_ptr(), D.data_ptr(), E._ptr(sym_err), wp, wn, st)
+    state = dict(cache=cache, tc=tc, x=x, flags=flags, sc=sc, coef=coef, cnoise=cnoise, cond=cond, saved=saved,
+                 tok_final=cur, B=B)
+    return D, state
+
+
+def _cond_chain_grads(model, cnoise, dcond):
+    """torch chain rule through PositionalEmbedding -> map_layer0 -> silu -> map_layer1 -> silu -> affine layers."""
+    C0 = model.embed_dim
+    mods = [model.patch_embed.affine]
+    for layer in list(model.down_layers) + list(model.up_layers):
+        mods += [blk.affine for blk in layer.blocks]
+    leaves = [model.map_layer0.weight, model.map_layer0.bias, model.map_layer1.weight, model.map_layer1.bias]
+    for m in mods:
+        leaves += [m.weight, m.bias]
+    det = [p.detach().requires_grad_(True) for p in leaves]
+    with torch.enable_grad():
+        half = C0 // 2
+        freqs = torch.arange(0, half, dtype=torch.float32, device=cnoise.device) / half
+        freqs = (1 / 10000) ** freqs
+        e = cnoise.detach().ger(freqs)
+        e = torch.cat([e.cos(), e.sin()], dim=1)
+        e = F.silu(F.linear(e, det[0], det[1]))
+        e = F.silu(F.linear(e, det[2], det[3]))
+        aw = torch.cat(det[4::2], dim=0)
+        ab = torch.cat(det[5::2], dim=0)
+        cond = F.linear(e, aw, ab)
+    grads = torch.autograd.grad(cond, det, grad_outputs=dcond)
+    return dict(zip([id(p) for p in leaves], grads))
+
+
+def _readout_chain_grads(model, p, dweff, dbeff):
+    """torch chain rule through engine.collapse_read_out (float64)."""
+    ro = model.read_out
+    leaves = [ro[0].weight, ro[0].bias, ro[1].weight, ro[1].bias, ro[2].weight, ro[2].bias]
+    det = [t.detach().double().requires_grad_(True) for t in leaves]
+    with torch.enable_grad():
+        W0, b0, W1, b1, W2, b2 = det
+        v = W2[0, :, 0, 0] @ W1[:, :, 0, 0]
+        weff = torch.einsum("o,ioyx->iyx", v, W0).reshape(W0.shape[0], p * p)
+        beff = v @ b0 + W2[0, :, 0, 0] @ b1 + b2[0]
+    grads = torch.autograd.grad([weff, beff], det, grad_outputs=[dweff.double(), dbeff.double()])
+    return dict(zip([id(t) for t in leaves], [g.float() for g in grads]))
+
+
+def backward_all(model, state, dD):
+    """-> {id(param): grad} for every parameter of `model`."""
+    cache, tc = state["cache"], state["tc"]
+    net = cache.net
+    B = state["B"]
+    dev = dD.device
+    dD = E._as_f32(dD)
+    st = E.stream_ptr()
+    ws = E.workspace(dev, max(cache.ws_bytes(B), tc.ws_bytes(cache, B)))
+    wp, wn = ws.data_ptr(), ws.numel()
+    f32 = dict(dtype=torch.float32, device=dev)
+    book = GradBook(model, dev)
+    names = _layer_names(model)
+    ct = net.cond_total
+    cond = state["cond"]
+    p = net.p
+    dro_w = torch.zeros((net.C0, p * p), **f32)
+    dro_b = torch.zeros((32,), **f32)
+    ends = L.SwgEndsTrain(tc.pe_wb.data_ptr(), book.ptr("patch_embed.proj.weight"), book.ptr("patch_embed.proj.bias"),
+                          _ln_train(book, "patch_embed.norm"), _ln_train(book, "norm"), tc.ro_wb.data_ptr(),
+                          dro_w.data_ptr(), dro_b.data_ptr())
+    tok_final = state["tok_final"]
+    dcur = torch.empty_like(tok_final)
+    _run(L.lib.swg_readout_sym_precond_bwd, "swg_readout_sym_precond_bwd", _c(net), _c(ends), B, tok_final.data_ptr(),
+         state["flags"].data_ptr(), state["coef"].data_ptr(), dD.data_ptr(), dcur.data_ptr(), wp, wn, st)
+    dcond = torch.zeros((B, ct), **f32)
+    dskips = {}
+    for entry in reversed(state["saved"]):
+        kind, li = entry[0], entry[1]
+        ly = cache.layers[li]
+        if kind == "down":
+            x_in = entry[2]
+            if li in dskips:
+                dcur = dcur.add_(dskips.pop(li))
+            pre = names[li] + ".downsample"
+            tr = L.SwgMergeTrain(_ln_train(book, pre + ".norm"), _lin_train(tc, book, pre + ".reduction", bias=False))
+            dx = torch.empty_like(x_in)
+            _run(L.lib.swg_patch_merge_bwd, "swg_patch_merge_bwd", ly.down, _c(tr), B, x_in.data_ptr(), dcur.data_ptr(),
+                 dx.data_ptr(), wp, wn, st)
+            dcur = dx
+        elif kind == "blk":
+            j, x_in, mid = entry[2], entry[3], entry[4]
+            pre = f"{names[li]}.blocks.{j}"
+            tr = L.SwgBlockTrain(_ln_train(book, pre + ".norm1"), _ln_train(book, pre + ".norm2"),
+                                 _lin_train(tc, book, pre + ".attn.qkv"), _lin_train(tc, book, pre + ".attn.proj"),
+                                 _lin_train(tc, book, pre + ".mlp.fc1"), _lin_train(tc, book, pre + ".mlp.fc2"),
+                                 book.ptr(pre + ".attn.relative_position_bias_table"))
+            blk = C.byref(ly.blocks[j])
+            dmid = torch.empty_like(mid)
+            _run(L.lib.swg_ln_mlp_bwd, "swg_ln_mlp_bwd", blk, _c(tr), B, mid.data_ptr(), dcur.data_ptr(), dmid.data_ptr(),
+                 wp, wn, st)
+            dx = torch.empty_like(x_in)
+            _run(L.lib.swg_wattn_bwd, "swg_wattn_bwd", blk, _c(tr), B, x_in.data_ptr(), cond.data_ptr(), ct,
+                 dmid.data_ptr(), dx.data_ptr(), dcond.data_ptr(), ct, wp, wn, st)
+            dcur = dx
+        else:  # "up"
+            si, x_in, skip = entry[2], entry[3], entry[4]
+            pre = names[li] + ".upsample"
+            tr = L.SwgBreakupTrain(_lin_train(tc, book, pre + ".pre_linear", bias=False), _ln_train(book, pre + ".norm"),
+                                   _ln_train(book, pre + ".post_norm"),
+                                   _lin_train(tc, book, pre + ".post_linear", bias=False))
+            dx, dskip = torch.empty_like(x_in), torch.empty_like(skip)
+            _run(L.lib.swg_patch_expand_bwd, "swg_patch_expand_bwd", ly.up, _c(tr), B, x_in.data_ptr(), skip.data_ptr(),
+                 dcur.data_ptr(), dx.data_ptr(), dskip.data_ptr(), wp, wn, st)
+            dskips[si] = dskip
+            dcur = dx
+    _run(L.lib.swg_patch_embed_bwd, "swg_patch_embed_bwd", _c(net), _c(ends), B, state["x"].data_ptr(),
+         E._ptr(state["sc"]), state["coef"].data_ptr() + 8, 4, cond.data_ptr(), ct, dcur.data_ptr(), dcond.data_ptr(), ct,
+         wp, wn, st)
+    out = {id(prm): book.views[name] for name, prm in model.named_parameters()}
+    out.update(_cond_chain_grads(model, state["cnoise"], dcond))
+    out.update(_readout_chain_grads(model, p, dro_w, dro_b[:p * p].sum()))
+    return out
+
+
+class DenoiserFn(torch.autograd.Function):
+    """D = Precond core (mode 1) or SwinGNN.forward (mode 0) with gradients to the module parameters."""
+
+    @staticmethod
+    def forward(ctx, model, mode, x, node_flags, labels, self_cond, sym_err, *params):
+        D, state = forward_keep(model, mode, x, node_flags, labels, self_cond, sym_err)
+        ctx.model, ctx.state, ctx.params = model, state, params
+        return D
+
+    @staticmethod
+    def backward(ctx, dD):
+        grads = backward_all(ctx.model, ctx.state, dD.contiguous())
+        ctx.state = None
+        return (None,) * 7 + tuple(grads[id(p)] if p.requires_grad else None for p in ctx.params)
+
+
+def denoise_with_grad(model, mode, x, node_flags, labels, self_cond, sym_err=None):
+    params = tuple(model.parameters())
+    return DenoiserFn.apply(model, mode, x, node_flags, labels, self_cond, sym_err, *params)

@@ -26,3 +26,14 @@ def golden_meta():
     import json
     with open(os.path.join(ROOT, "tests", "golden", "golden_meta.json")) as f:
         return json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_train():
+    """Train-step goldens (loss + gradient fingerprints) from the reference modules (tests/golden/make_golden_train.py)."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "golden_train.npz")
+    with np.load(path, allow_pickle=False) as z:
+        arrays = {k: z[k] for k in z.files}
+    with open(os.path.join(ROOT, "tests", "golden", "golden_train_meta.json")) as f:
+        return arrays, json.load(f)

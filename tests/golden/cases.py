@@ -66,3 +66,9 @@ SAMPLER_CASES = {
     "ego60_sanity": dict(net="ego60", regime="init", steps=16, B=3, n_lo=4, n_hi=18, sanity=True, seed=63),
     "grid192_4": dict(net="grid192", regime="init", steps=4, B=1, n_lo=100, n_hi=181, sanity=False, seed=64),
 }
+
+# G9: train step (loss [B] + every parameter gradient) of RainbowLoss(Precond(SwinGNN)(x, flags, sigmas), sign(x)).mean()
+# (network case, weight regime, sigma index, outcome of the self-conditioning coin)
+TRAIN_CASES = [("com96", "stress", 0, True), ("com96", "init", 1, False), ("ego60", "stress", 1, True),
+               ("grid192", "stress", 0, True), ("ego60_nosc", "stress", 0, False), ("grid192", "init", 1, True),
+               ("ego60", "init", 0, True)]

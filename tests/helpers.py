@@ -78,3 +78,23 @@ def net_inputs(case, si):
 
 def max_abs(a, b):
     return float((torch.as_tensor(a) - torch.as_tensor(b)).abs().max())
+
+
+def oracle_grads(sd, cfg, x, flags, sig, w, clean, coin):
+    """Loss [B] and every parameter gradient of mean(edm_loss(precond_forward(...))) by autograd through the oracle."""
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+    full = dict(sd)
+    full.update(leaves)
+    with torch.enable_grad():
+        D = O.precond_forward(full, cfg, x, flags, sig, coin)
+        loss = O.edm_loss(D, clean, flags, w)
+        loss.mean().backward()
+    return loss.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}
+
+
+def train_case_inputs(case, si):
+    """Inputs of a TRAIN_CASES entry: flags, noisy x, sigmas, loss weights, clean target."""
+    flags, x, sig, _ = net_inputs(case, si)
+    clean = O.mask_adjs(torch.sign(x), flags)
+    w = (sig ** 2 + 0.25) / (sig * 0.5) ** 2
+    return flags, x, sig, w, clean

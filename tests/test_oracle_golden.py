@@ -130,3 +130,33 @@ def test_objective_and_loss(golden):
     close(noisy, golden["objective/noisy"])
     pred = filler.sym_adj("pred", B, N, flags, 4)
     close(O.edm_loss(pred, clean, flags, w), golden["objective/loss"])
+
+
+# ---- G9: train step (row a20): autograd through the oracle against the reference's loss.backward() ----
+from tests.golden.cases import TRAIN_CASES  # noqa: E402
+
+
+@pytest.mark.parametrize("name,regime,si,coin", TRAIN_CASES)
+def test_oracle_train_step_gradients(golden_meta, golden_train, name, regime, si, coin):
+    arrays, meta = golden_train
+    c = NET_CASES[name]
+    sd = H.net_state(golden_meta[f"keys/{name}"], c["seed"], regime)
+    flags, x, sig, w, clean = H.train_case_inputs(c, si)
+    loss, grads = H.oracle_grads(sd, c["cfg"], x, flags, sig, w, clean, coin)
+    key = f"train/{name}/{regime}/s{si}/coin{int(coin)}"
+    np.testing.assert_allclose(loss.numpy(), arrays[key + "/loss"], rtol=2e-5, atol=1e-7)
+    names = meta["param_names/" + name]
+    g = [grads[k].double() for k in names]
+    total = float(torch.sqrt(sum((t ** 2).sum() for t in g)))
+    assert abs(total - float(arrays[key + "/grad_norm"])) <= 1e-4 * total
+    abs_sums = np.array([float(t.abs().sum()) for t in g])
+    sums = np.array([float(t.sum()) for t in g])
+    ref_abs = arrays[key + "/grad_abs_sums"]
+    np.testing.assert_allclose(abs_sums, ref_abs, rtol=2e-3, atol=1e-6 * float(ref_abs.max()))
+    np.testing.assert_allclose(sums, arrays[key + "/grad_sums"], rtol=0, atol=2e-3 * float(ref_abs.max()))
+    for k in names:
+        gk = f"{key}/grad/{k}"
+        if gk in arrays:
+            ref = arrays[gk]
+            err = np.abs(grads[k].numpy() - ref).max()
+            assert err <= 1e-3 * max(np.abs(ref).max(), 1e-6), (k, err)
