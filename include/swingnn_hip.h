@@ -270,6 +270,27 @@ int swg_edm_loss_bwd(int32_t B, int32_t N, const float* pred, const float* targe
                      const float* weights, const float* grad_loss, float regression_loss_weight, float* grad_pred,
                      void* stream);
 
+/* ---- optimizer tail of the train step (runner/trainer/trainer.py:136-140) ---------------- *
+ * Multi-tensor kernels over all parameters.  p_ptrs / g_ptrs: DEVICE arrays of n_tensors fp32 pointers (the
+ * nn.Parameters and their .grad); numel [n_tensors] int32; flat_off [n_tensors] int64 = offset of the tensor inside
+ * the flat moment / EMA buffers; (chunk_tensor, chunk_off) [n_chunks] int32: chunk c covers elements
+ * [chunk_off[c], chunk_off[c] + swg_optim_chunk()) of tensor chunk_tensor[c].  All tables are device memory.
+ * swg_grad_sqnorm: *sqnorm = sum of squares of every gradient element (the call zeroes it first) --
+ *   torch.nn.utils.clip_grad_norm_(norm_type=2) before the scaling.
+ * swg_adam_ema_step: g <- g * min(1, max_norm / (sqrt(*sqnorm) + 1e-6)) when sqnorm != NULL (clip_grad_norm_,
+ *   :136); torch.optim.Adam update with bias correction at step `step` >= 1 (utils/learning_utils.py:245-248;
+ *   weight_decay is Adam's L2 term); then for k < n_ema (<= 8): ema_k <- lerp(ema_k, p, 1 - ema_decay[k])
+ *   (ema_pytorch's update_moving_average as used at :268; ema_decay is a HOST array, decay 0 = copy).
+ *   m, v [total]; ema [n_ema, total] fp32. */
+int swg_optim_chunk(void);
+int swg_grad_sqnorm(const void* g_ptrs, const int32_t* numel, const int32_t* chunk_tensor, const int32_t* chunk_off,
+                    int32_t n_chunks, float* sqnorm, void* stream);
+int swg_adam_ema_step(const void* p_ptrs, const void* g_ptrs, const int32_t* numel, const int64_t* flat_off,
+                      const int32_t* chunk_tensor, const int32_t* chunk_off, int32_t n_chunks, float* m, float* v,
+                      float* ema, int64_t total, int32_t n_ema, const float* ema_decay, const float* sqnorm,
+                      float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                      void* stream);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------------------- *
  * When enabled, every internal kernel launch is bracketed by HIP events on its stream and its
  * algorithmic FLOPs / bytes are tallied per kernel.  swg_prof_read synchronises the recorded events.

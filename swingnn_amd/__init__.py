@@ -10,6 +10,8 @@ from .swin_gnn import (SwinGNN, SwinTransformerBlock, WindowAttention, PatchMerg
 from .precond import Precond
 from .edm_sampler import EDMSampler, GeneralSampler
 from .objective import EDMObjectiveGenerator, RainbowLoss
+from .optim import FusedAdamEMA
 
 __all__ = ["SwinGNN", "SwinTransformerBlock", "WindowAttention", "PatchMerging", "PatchBreakup", "PatchEmbed",
-           "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler", "EDMObjectiveGenerator", "RainbowLoss"]
+           "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler", "EDMObjectiveGenerator", "RainbowLoss",
+           "FusedAdamEMA"]

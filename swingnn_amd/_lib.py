@@ -116,6 +116,10 @@ SYMBOLS = {
     "swg_readout_sym_precond_bwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgEndsTrain), _i32, _fp, _fp, _fp, _fp, _fp,
                                               _fp, _sz, _fp]),
     "swg_edm_loss_bwd": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _fp, _fp]),
+    "swg_optim_chunk": (C.c_int, []),
+    "swg_grad_sqnorm": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _fp, _fp]),
+    "swg_adam_ema_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _fp, _fp, _fp, C.c_int64, _i32,
+                                    C.POINTER(C.c_float), _fp, _f, _f, _f, _f, _f, _f, _i32, _fp]),
     "swg_prof_enable": (C.c_int, [_i32]),
     "swg_prof_reset": (C.c_int, []),
     "swg_prof_kernels": (C.c_int, []),

@@ -1,0 +1,129 @@
+// Optimizer tail of the train step (runner/trainer/trainer.py:136-140) as two multi-tensor kernels over every
+// parameter of the model: (1) the global L2 gradient norm of clip_grad_norm_(max_norm, norm_type=2), (2) gradient
+// scaling by the clip coefficient + Adam (utils/learning_utils.py:245-248: betas, eps, L2 weight decay) + the
+// exponential moving averages of the parameters (:253-274), one read of p / g / m / v and of each EMA copy, one
+// write of p / m / v and each EMA copy.  HBM-bound: 4 B x (4 reads + 3 writes + 2 per EMA) per parameter.
+//
+// Parameters and gradients stay the caller's separate tensors (ordinary nn.Parameters); they are addressed through
+// device pointer tables.  Work is cut into chunks of CHUNK elements; chunk c belongs to tensor chunk_tensor[c] and
+// starts at element chunk_off[c].  Moments and EMA copies live in flat buffers at flat_off[tensor].
+#include "common.h"
+
+namespace {
+
+constexpr int CHUNK = 2048;  // elements per workgroup: 256 threads x 2 float4
+
+__global__ __launch_bounds__(256) void k_grad_sqnorm(const float* const* __restrict__ g_ptrs,
+                                                     const int32_t* __restrict__ numel,
+                                                     const int32_t* __restrict__ chunk_tensor,
+                                                     const int32_t* __restrict__ chunk_off, float* __restrict__ sqnorm) {
+  __shared__ float red[4];
+  const int c = blockIdx.x;
+  const int t = chunk_tensor[c];
+  const int off = chunk_off[c];
+  const int n = min(CHUNK, numel[t] - off);
+  const float* g = g_ptrs[t] + off;
+  float s = 0.f;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    const float v = g[i];
+    s += v * v;
+  }
+  s = group_sum<64>(s);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+  __syncthreads();
+  if (threadIdx.x == 0) atomicAdd(sqnorm, red[0] + red[1] + red[2] + red[3]);
+}
+
+struct AdamArgs {
+  float* const* p_ptrs;
+  const float* const* g_ptrs;
+  const int32_t* numel;
+  const int64_t* flat_off;
+  const int32_t* chunk_tensor;
+  const int32_t* chunk_off;
+  float* m;
+  float* v;
+  float* ema;
+  int64_t total;
+  int n_ema;
+  float ema_w[8];  // 1 - decay_k (1 = copy)
+  const float* sqnorm;
+  float max_norm, lr, b1, b2, eps, wd;
+  float bc1, bc2s;  // 1 - b1^t, sqrt(1 - b2^t)
+};
+
+__global__ __launch_bounds__(256) void k_adam_ema(AdamArgs a) {
+  const int c = blockIdx.x;
+  const int t = a.chunk_tensor[c];
+  const int off = a.chunk_off[c];
+  const int n = min(CHUNK, a.numel[t] - off);
+  float* p = a.p_ptrs[t] + off;
+  const float* g = a.g_ptrs[t] + off;
+  const int64_t fo = a.flat_off[t] + off;
+  float clip = 1.f;
+  if (a.sqnorm) {  // torch.nn.utils.clip_grad_norm_: coef = max_norm / (norm + 1e-6), clamped to 1
+    clip = fminf(a.max_norm / (sqrtf(*a.sqnorm) + 1e-6f), 1.0f);
+  }
+  const float step = a.lr / a.bc1;
+  for (int i = threadIdx.x; i < n; i += 256) {
+    float pv = p[i];
+    float gv = g[i] * clip;
+    if (a.wd != 0.f) gv = fmaf(a.wd, pv, gv);
+    const float mv = a.b1 * a.m[fo + i] + (1.f - a.b1) * gv;
+    const float vv = a.b2 * a.v[fo + i] + (1.f - a.b2) * gv * gv;
+    a.m[fo + i] = mv;
+    a.v[fo + i] = vv;
+    pv -= step * mv / (sqrtf(vv) / a.bc2s + a.eps);
+    p[i] = pv;
+    for (int k = 0; k < a.n_ema; ++k) {
+      float* e = a.ema + (int64_t)k * a.total + fo + i;
+      const float ev = *e;
+      *e = ev + a.ema_w[k] * (pv - ev);  // lerp(ema, p, 1 - decay)
+    }
+  }
+}
+
+}  // namespace
+
+extern "C" {
+
+int swg_grad_sqnorm(const void* g_ptrs, const int32_t* numel, const int32_t* chunk_tensor, const int32_t* chunk_off,
+                    int32_t n_chunks, float* sqnorm, void* stream) {
+  if (!g_ptrs || !numel || !chunk_tensor || !chunk_off || !sqnorm) return SWG_E_NULL;
+  if (n_chunks <= 0) return SWG_E_SHAPE;
+  hipStream_t s = (hipStream_t)stream;
+  hipError_t he = hipMemsetAsync(sqnorm, 0, sizeof(float), s);
+  if (he != hipSuccess) return (int)he;
+  SwgProfScope ps(KID_OPTIM, 0.0, 4.0 * n_chunks * (double)CHUNK, s);
+  hipLaunchKernelGGL(k_grad_sqnorm, dim3(n_chunks), dim3(256), 0, s, (const float* const*)g_ptrs, numel, chunk_tensor,
+                     chunk_off, sqnorm);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_adam_ema_step(const void* p_ptrs, const void* g_ptrs, const int32_t* numel, const int64_t* flat_off,
+                      const int32_t* chunk_tensor, const int32_t* chunk_off, int32_t n_chunks, float* m, float* v,
+                      float* ema, int64_t total, int32_t n_ema, const float* ema_decay, const float* sqnorm,
+                      float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
+                      void* stream) {
+  if (!p_ptrs || !g_ptrs || !numel || !flat_off || !chunk_tensor || !chunk_off || !m || !v) return SWG_E_NULL;
+  if (n_chunks <= 0 || step < 1 || n_ema < 0 || n_ema > 8 || total <= 0) return SWG_E_SHAPE;
+  if (n_ema > 0 && (!ema || !ema_decay)) return SWG_E_NULL;
+  AdamArgs a = {};
+  a.p_ptrs = (float* const*)p_ptrs; a.g_ptrs = (const float* const*)g_ptrs;
+  a.numel = numel; a.flat_off = flat_off; a.chunk_tensor = chunk_tensor; a.chunk_off = chunk_off;
+  a.m = m; a.v = v; a.ema = ema; a.total = total; a.n_ema = n_ema;
+  for (int k = 0; k < n_ema; ++k) a.ema_w[k] = 1.0f - ema_decay[k];
+  a.sqnorm = sqnorm; a.max_norm = max_norm; a.lr = lr; a.b1 = beta1; a.b2 = beta2; a.eps = eps; a.wd = weight_decay;
+  a.bc1 = (float)(1.0 - pow((double)beta1, (double)step));
+  a.bc2s = (float)sqrt(1.0 - pow((double)beta2, (double)step));
+  hipStream_t s = (hipStream_t)stream;
+  SwgProfScope ps(KID_OPTIM, 0.0, 4.0 * n_chunks * (double)CHUNK * (7.0 + 2.0 * n_ema), s);
+  hipLaunchKernelGGL(k_adam_ema, dim3(n_chunks), dim3(256), 0, s, a);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_optim_chunk(void) { return CHUNK; }
+
+}  // extern "C"

@@ -83,6 +83,7 @@ class GradBook:
             spans.append((name, off, p.shape))
             off += (p.numel() + 63) // 64 * 64
         self.flat = torch.zeros(off + 64, dtype=torch.float32, device=device)
+        self.offset = {name: o for name, o, _ in spans}
         for name, o, shape in spans:
             n = 1
             for d in shape:
@@ -226,12 +227,21 @@ def backward_all(model, state, dD):
     B = state["B"]
     dev = dD.device
     dD = E._as_f32(dD)
+    sync = getattr(model, "_swg_grad_sync", None)
+    if sync is not None:  # data parallel: sum over ranks of (dD / W)-gradients = the DDP average
+        dD = dD / sync.world_size
     st = E.stream_ptr()
     ws = E.workspace(dev, max(cache.ws_bytes(B), tc.ws_bytes(cache, B)))
     wp, wn = ws.data_ptr(), ws.numel()
     f32 = dict(dtype=torch.float32, device=dev)
     book = GradBook(model, dev)
     names = _layer_names(model)
+    if sync is not None:
+        sync.begin(book.flat)
+    first_of = {}  # flat offset of the first parameter of every module prefix (modules own contiguous slices)
+    for pname, o in book.offset.items():
+        for depth in (2, 3, 4):
+            first_of.setdefault(".".join(pname.split(".")[:depth]), o)
     ct = net.cond_total
     cond = state["cond"]
     p = net.p
@@ -285,12 +295,19 @@ def backward_all(model, state, dD):
                  dcur.data_ptr(), dx.data_ptr(), dskip.data_ptr(), wp, wn, st)
             dskips[si] = dskip
             dcur = dx
+        if sync is not None:  # this module and everything after it in parameter order is complete
+            sync.ready_from(first_of[pre])
     _run(L.lib.swg_patch_embed_bwd, "swg_patch_embed_bwd", _c(net), _c(ends), B, state["x"].data_ptr(),
          E._ptr(state["sc"]), state["coef"].data_ptr() + 8, 4, cond.data_ptr(), ct, dcur.data_ptr(), dcond.data_ptr(), ct,
          wp, wn, st)
     out = {id(prm): book.views[name] for name, prm in model.named_parameters()}
-    out.update(_cond_chain_grads(model, state["cnoise"], dcond))
-    out.update(_readout_chain_grads(model, p, dro_w, dro_b[:p * p].sum()))
+    small = _cond_chain_grads(model, state["cnoise"], dcond)
+    small.update(_readout_chain_grads(model, p, dro_w, dro_b[:p * p].sum()))
+    if sync is not None:
+        keys = list(small)
+        vals = sync.finish([small[k].contiguous() for k in keys])
+        small = dict(zip(keys, vals))
+    out.update(small)
     return out
 
 

@@ -63,3 +63,61 @@ def test_train_step_gradients(golden_meta, name, regime, si, coin, monkeypatch):
             bad.append((k, rel, cos, nr))
     assert not bad, bad
     assert abs(got_total ** 0.5 - total) <= norm_tol * total, (got_total ** 0.5, total)
+
+
+def test_fused_adam_ema_matches_torch():
+    """clip_grad_norm_ + torch.optim.Adam + lerp EMAs (torch fp32 on the GPU) against the two fused kernels."""
+    import swingnn_amd as S
+    torch.manual_seed(3)
+    shapes = [(363,), (96, 32), (5, 7, 3), (4097,), (1,), (288, 96)]
+    ref_p = [torch.nn.Parameter(torch.randn(s, device=DEV)) for s in shapes]
+    my_p = [torch.nn.Parameter(p.detach().clone()) for p in ref_p]
+    betas = (0.9, 0.99, 0.999)
+    ref_opt = torch.optim.Adam(ref_p, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01)
+    my_opt = S.FusedAdamEMA(my_p, lr=1e-2, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.01, max_norm=10.0, ema_betas=betas)
+    ref_ema = [[p.detach().clone() for p in ref_p] for _ in betas]
+    versions = [p._version for p in my_p]
+    for it in range(1, 6):
+        scale = 30.0 if it % 2 else 0.01  # clipped and unclipped steps
+        for rp, mp in zip(ref_p, my_p):
+            g = torch.randn_like(rp) * scale
+            rp.grad, mp.grad = g.clone(), g.clone()
+        total = torch.nn.utils.clip_grad_norm_(ref_p, max_norm=10.0, norm_type=2)
+        ref_opt.step()
+        my_opt.step()
+        assert abs(float(my_opt.grad_norm()) - float(total)) <= 1e-5 * float(total)
+        dec = [0.0 if it <= 2 else min(max(1.0 - 1.0 / (1.0 + (it - 1)), 0.0), b) for b in betas]
+        with torch.no_grad():
+            for k, d in enumerate(dec):
+                for e, rp in zip(ref_ema[k], ref_p):
+                    e.lerp_(rp.detach(), 1.0 - d)
+        for rp, mp in zip(ref_p, my_p):
+            assert torch.allclose(mp, rp, rtol=2e-6, atol=2e-7), float((mp - rp).abs().max())
+        for k in range(len(betas)):
+            for e, me in zip(ref_ema[k], my_opt.ema_parameters(k)):
+                assert torch.allclose(me, e, rtol=2e-6, atol=2e-7)
+    assert all(p._version > v for p, v in zip(my_p, versions))
+
+
+def test_train_steps_reduce_loss(golden_meta, monkeypatch):
+    """Three full train steps (objective -> Precond forward -> loss -> backward -> clip + Adam + EMA) on one batch:
+    the loss on that batch goes down and the weight caches follow the updated parameters."""
+    import swingnn_amd as S
+    from tests.test_gpu_parity import build_precond
+    c = NET_CASES["com96"]
+    pre = build_precond(S, "com96", golden_meta, "init").train()
+    flags, x, sig, w, clean = (t.to(DEV) for t in H.train_case_inputs(c, 1))
+    opt = S.FusedAdamEMA(pre.parameters(), lr=1e-3, max_norm=10.0, ema_betas=(0.9, 0.99))
+    loss_fn = S.RainbowLoss(1.0, False, "edm")
+    monkeypatch.setattr(np.random, "rand", lambda: 0.75)
+    losses = []
+    with torch.enable_grad():
+        for _ in range(4):
+            opt.zero_grad(set_to_none=True)
+            D = pre(x=x, node_flags=flags, sigmas=sig)
+            loss = loss_fn(D, clean, sig, x, clean, flags, loss_weight=w, reduction='none').mean()
+            loss.backward()
+            opt.step()
+            losses.append(float(loss.detach()))
+    assert all(np.isfinite(losses)), losses
+    assert losses[-1] < losses[0], losses
