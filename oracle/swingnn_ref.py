@@ -367,3 +367,151 @@ def threshold_adj(x, node_flags):
     """Post-sampling quantisation: clamp(-1,1), then 2-type ddpm->int (x > 0), masked.
     runner/sampler/sampler.py:131-135, utils/attribute_code.py:133-159."""
     return mask_adjs((x.clamp(-1.0, 1.0) > 0).to(torch.float32), node_flags)
+
+
+# --------------------------------------------------------------------------------------
+# node + adjacency (molecule) variants: NodeAdjSwinGNN / NodeAdjPrecond / NodeAdjEDMSampler
+# --------------------------------------------------------------------------------------
+def mask_nodes(nodes: torch.Tensor, flags: torch.Tensor) -> torch.Tensor:
+    """Zero node rows whose flag is 0; out-of-place.  utils/graph_utils.py:41-86 (along_dim=None)."""
+    keep = flags.to(torch.bool)
+    if nodes.dim() == 3:
+        keep = keep[..., None]
+    return nodes * keep.to(nodes.dtype)
+
+
+def _adj4(a):
+    return a[:, None] if a.dim() == 3 else a                      # swin_gnn.py:966-969
+
+
+def _feat3(f):
+    return f[:, None] if f.dim() == 2 else f.permute(0, 2, 1)     # swin_gnn.py:971-976 -> [B, C, N]
+
+
+def nodeadj_forward(sd, cfg, adj, node, node_flags, noise_labels, sc_adj=None, sc_node=None):
+    """NodeAdjSwinGNN.forward, model/swin_gnn/swin_gnn.py:960-1021.
+    adj [B,N,N] | [B,Ca,N,N], node [B,N] | [B,N,Cn] -> (adj_out same layout, node_out same layout).
+    cfg carries out_chans_adj / out_chans_node besides the SwinGNN keys."""
+    emb = noise_embedding(noise_labels, sd, cfg["embed_dim"])
+    a = _adj4(adj)
+    f = _feat3(node.to(torch.float32))
+    if cfg["self_condition"]:
+        a = torch.cat([torch.zeros_like(a) if sc_adj is None else _adj4(sc_adj), a], dim=1)        # :985-986
+        f = torch.cat([torch.zeros_like(f) if sc_node is None else _feat3(sc_node), f], dim=1)     # :987-988
+    N = f.shape[-1]
+    nm = f[..., None].expand(-1, -1, -1, N)                                                        # :991  [B,C,N,N], value of row i
+    nm = mask_adjs(torch.cat([nm, nm.transpose(-1, -2)], dim=1), node_flags)                       # :992-994
+    img = torch.cat([a, nm], dim=1)                                                                # :996
+    p = cfg["patch_size"]
+    x = patch_embed(img, emb, sd, "patch_embed", p)
+    skips = []
+    for st in stages(cfg):
+        if not st["up"] and st["prefix"].startswith("up_layers"):
+            skips.pop()
+        if st["up"]:
+            x = patch_breakup(torch.cat([x, skips.pop()], dim=-1), sd, st["prefix"] + ".upsample", st["res"] // 2)
+        for j in range(st["depth"]):
+            shift = 0 if j % 2 == 0 else cfg["window_size"] // 2
+            x = swin_block(x, emb, sd, f"{st['prefix']}.blocks.{j}", st["res"], st["heads"], cfg["window_size"], shift)
+        if st["down"]:
+            x = patch_merging(x, sd, st["prefix"] + ".downsample", st["res"])
+        if st["prefix"].startswith("down_layers"):
+            skips.append(x)
+    x = _ln(x, sd, "norm")
+    B, L, C = x.shape
+    res = cfg["img_size"] // p
+    y = x.reshape(B, res, res, C).permute(0, 3, 1, 2)
+    y = F.conv_transpose2d(y, sd["read_out.0.weight"], sd["read_out.0.bias"], stride=p)
+    y = F.conv2d(y, sd["read_out.1.weight"], sd["read_out.1.bias"])
+    rep = F.conv2d(y, sd["read_out.2.weight"], sd["read_out.2.bias"])                              # [B, C, N, N]  :955-956
+
+    def mlp(t, pfx):
+        return _lin(F.gelu(_lin(t, sd, pfx + ".fc1")), sd, pfx + ".fc2")
+
+    ao = mlp(rep.permute(0, 2, 3, 1), "readout_adj_mlp")                                           # :1000-1003
+    ao = ao.squeeze(-1) if cfg["out_chans_adj"] == 1 else ao.permute(0, 3, 1, 2)
+    pooled = mask_adjs(rep, node_flags).mean(dim=-1)                                               # :1006-1007 [B, C, N]
+    no = mlp(pooled.permute(0, 2, 1), "readout_node_mlp")                                          # :1009-1012
+    no = no.squeeze(-1) if cfg["out_chans_node"] == 1 else no
+    no = mask_nodes(no, node_flags)
+    ao = mask_adjs(ao, node_flags)
+    return 0.5 * (ao + ao.transpose(-1, -2)), no                                                   # :1015-1018
+
+
+def nodeadj_precond_forward(sd, cfg, adjs, nodes, node_flags, sigmas, coin: bool, sc_adjs=None, sc_nodes=None):
+    """NodeAdjPrecond.forward, model/precond/precond.py:65-110.  Unlike Precond.forward the passed-in
+    self-conditioning tensors ARE used (:81-82) unless the coin replaces them (:90-98)."""
+    net = _strip(sd)
+    c_skip, c_out, c_in, c_noise = edm_coefficients(sigmas)
+    ca = (lambda c: c.reshape(-1, 1, 1, 1)) if adjs.dim() == 4 else (lambda c: c.reshape(-1, 1, 1))
+    cf = (lambda c: c.reshape(-1, 1)) if nodes.dim() == 2 else (lambda c: c.reshape(-1, 1, 1))
+    if cfg["self_condition"] and coin:
+        with torch.no_grad():
+            sa, sn = nodeadj_forward(net, cfg, ca(c_in) * adjs, cf(c_in) * nodes, node_flags, c_noise, sc_adjs, sc_nodes)
+            sc_adjs = mask_adjs(ca(c_skip) * adjs + ca(c_out) * sa, node_flags)
+            sc_nodes = mask_nodes(cf(c_skip) * nodes + cf(c_out) * sn, node_flags)
+    Fa, Fn = nodeadj_forward(net, cfg, ca(c_in) * adjs, cf(c_in) * nodes, node_flags, c_noise, sc_adjs, sc_nodes)
+    return (mask_adjs(ca(c_skip) * adjs + ca(c_out) * Fa, node_flags),
+            mask_nodes(cf(c_skip) * nodes + cf(c_out) * Fn, node_flags))
+
+
+def nodeadj_gen_init_sample(node_flags, num_node_chan, num_edge_chan, raw_adj=None, raw_node=None):
+    """NodeAdjEDMSampler.gen_init_sample (symmetric noise, folded_norm=False as sample() calls it),
+    runner/mcmc_sampler/edm.py:261-293."""
+    B, N = node_flags.shape
+    if raw_adj is None:
+        raw_adj = torch.randn((B, num_edge_chan, N, N))
+    if raw_node is None:
+        raw_node = torch.randn((B, N, num_node_chan))
+    a = raw_adj.triu(diagonal=1)
+    a = mask_adjs(a + a.transpose(-1, -2), node_flags)
+    n = mask_nodes(raw_node, node_flags)
+    return (a.squeeze(1) if num_edge_chan == 1 else a), (n.squeeze(-1) if num_node_chan == 1 else n)
+
+
+def nodeadj_edm_sample(denoiser, node_flags, init_adjs, init_nodes, num_steps=256, self_condition=True,
+                       noise_fn=None, sanity_gt=None, S_churn=40.0, S_min=0.05, S_max=50.0, S_noise=1.003):
+    """NodeAdjEDMSampler.sample with the shipped defaults (heun, linear schedule, no scaling, alpha=1, symmetric
+    noise); runner/mcmc_sampler/edm.py:295-449.  ``denoiser(adjs, nodes, flags, sigmas, sc_adjs, sc_nodes)``;
+    ``noise_fn(x)`` supplies the raw normals of randn_like, called for the adjacency first and then the nodes
+    (:362-368)."""
+    noise_fn = noise_fn or torch.randn_like
+    t = edm_sigma_steps(num_steps)
+    a_next, n_next = init_adjs * t[0], init_nodes * t[0]
+    sca = scn = None
+    B = node_flags.shape[0]
+    for i in range(num_steps):
+        t_cur, t_next = t[i], t[i + 1]
+        gamma = min(S_churn / num_steps, np.sqrt(2) - 1) if S_min <= t_cur <= S_max else 0         # :359
+        t_hat = torch.as_tensor(t_cur + gamma * t_cur)
+        k = (t_hat ** 2 - t_cur ** 2).clip(min=0).sqrt() * S_noise
+        a_hat = mask_adjs(a_next + k * sym_noise_from_raw(noise_fn(a_next)), node_flags)           # :362-363, :369
+        n_hat = mask_nodes(n_next + k * noise_fn(n_next), node_flags)                              # :367-370
+        h = t_next - t_hat
+        sig = t_hat.reshape(-1).expand(B)
+        if sanity_gt is None:
+            da, dn = denoiser(a_hat, n_hat, node_flags, sig, sca, scn)                             # :378
+        else:
+            da, dn = sanity_gt
+        da, dn = mask_adjs(da, node_flags), mask_nodes(dn, node_flags)
+        dca = mask_adjs((1 / t_hat) * a_hat - (1 / t_hat) * da, node_flags)                        # :388-391
+        dcn = mask_nodes((1 / t_hat) * n_hat - (1 / t_hat) * dn, node_flags)
+        a_pr, n_pr = a_hat + h * dca, n_hat + h * dcn
+        t_prime = t_hat + h
+        if i == num_steps - 1:
+            a_next, n_next = a_hat + h * dca, n_hat + h * dcn                                      # :398-400
+        else:
+            if sanity_gt is None:
+                scn = dn if self_condition else None                                               # :406-407
+                sca = da if self_condition else None
+                da, dn = denoiser(a_hat, n_hat, node_flags, sig, sca, scn)                         # :409 (sic: *_hat, t_hat)
+            da, dn = mask_adjs(da, node_flags), mask_nodes(dn, node_flags)
+            dpn = (1 / t_prime) * n_pr - (1 / t_prime) * dn                                        # :418-421
+            dpa = (1 / t_prime) * a_pr - (1 / t_prime) * da
+            n_next = n_hat + h * (0.5 * dcn + 0.5 * dpn)                                           # :422-423
+            a_next = a_hat + h * (0.5 * dca + 0.5 * dpa)
+        a_next, n_next = mask_adjs(a_next, node_flags), mask_nodes(n_next, node_flags)             # :425-426
+        sca = da if self_condition else None                                                       # :427-428
+        scn = dn if self_condition else None
+        assert symmetry_residual(a_next) < 1e-2                                                    # :429-430
+    return a_next, n_next

@@ -37,3 +37,15 @@ def golden_train():
         arrays = {k: z[k] for k in z.files}
     with open(os.path.join(ROOT, "tests", "golden", "golden_train_meta.json")) as f:
         return arrays, json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_nodeadj():
+    """Molecule-path goldens (NodeAdjSwinGNN / NodeAdjPrecond / NodeAdjEDMSampler) from the reference modules
+    (tests/golden/make_golden_nodeadj.py)."""
+    import json
+    path = os.path.join(ROOT, "tests", "golden", "golden_nodeadj.npz")
+    with np.load(path, allow_pickle=False) as z:
+        arrays = {k: z[k] for k in z.files}
+    with open(os.path.join(ROOT, "tests", "golden", "golden_nodeadj_meta.json")) as f:
+        return arrays, json.load(f)

@@ -72,3 +72,32 @@ SAMPLER_CASES = {
 TRAIN_CASES = [("com96", "stress", 0, True), ("com96", "init", 1, False), ("ego60", "stress", 1, True),
                ("grid192", "stress", 0, True), ("ego60_nosc", "stress", 0, False), ("grid192", "init", 1, True),
                ("ego60", "init", 0, True)]
+
+
+# G10: NodeAdjSwinGNN / NodeAdjPrecond / NodeAdjEDMSampler (molecule path).  in_chans = 2*Cn + Ca before the
+# self-conditioning doubling (utils/learning_utils.py:184-214); adjacency [B,N,N] when Ca == 1 else [B,Ca,N,N],
+# node features [B,N] when Cn == 1 else [B,N,Cn].
+def _na_cfg(img, p, dim, depths, window, Ca, Cn, self_cond=True):
+    return dict(img_size=img, patch_size=p, in_chans=2 * Cn + Ca, embed_dim=dim, depths=depths, num_heads=HEADS,
+                window_size=window, self_condition=self_cond, out_chans_adj=Ca, out_chans_node=Cn)
+
+
+NODEADJ_CASES = {
+    # config/edm_swin_gnn/qm9_edm_swin_gnn.yaml as shipped: ddpm encodings (1 + 1 channels), dim 60
+    "qm9_ddpm60": dict(cfg=_na_cfg(16, 1, 60, [1, 1, 3, 1], 4, 1, 1), B=4, n_lo=3, n_hi=9, sigmas=[0.3, 8.0],
+                       regimes=["init", "stress"], seed=71),
+    # one-hot node / edge attributes (4 + 4 channels), dim 96 (BASELINE.json configs[2])
+    "qm9_onehot96": dict(cfg=_na_cfg(16, 1, 96, [1, 1, 3, 1], 4, 4, 4), B=3, n_lo=3, n_hi=9, sigmas=[1.0],
+                         regimes=["stress"], seed=72),
+    # zinc250k geometry: N=48, patch 3, window 2 (token sides 16/8/4/2; the middle block of the depth-3 stage is shifted)
+    "zinc_ddpm96": dict(cfg=_na_cfg(48, 3, 96, [1, 1, 3, 1], 2, 1, 1), B=2, n_lo=10, n_hi=38, sigmas=[2.0],
+                        regimes=["stress"], seed=73),
+    "qm9_ddpm60_nosc": dict(cfg=_na_cfg(16, 1, 60, [1, 1, 3, 1], 4, 1, 1, self_cond=False), B=2, n_lo=3, n_hi=9,
+                            sigmas=[1.0], regimes=["stress"], seed=74),
+}
+
+NODEADJ_SAMPLER_CASES = {
+    "qm9_ddpm60_6": dict(net="qm9_ddpm60", regime="init", steps=6, B=3, n_lo=3, n_hi=9, sanity=False, seed=81),
+    "qm9_onehot96_4": dict(net="qm9_onehot96", regime="init", steps=4, B=2, n_lo=3, n_hi=9, sanity=False, seed=82),
+    "qm9_ddpm60_sanity": dict(net="qm9_ddpm60", regime="init", steps=12, B=3, n_lo=3, n_hi=9, sanity=True, seed=83),
+}

@@ -98,3 +98,21 @@ def train_case_inputs(case, si):
     clean = O.mask_adjs(torch.sign(x), flags)
     w = (sig ** 2 + 0.25) / (sig * 0.5) ** 2
     return flags, x, sig, w, clean
+
+
+def nodeadj_inputs(cfg, B, flags, seed, sigma):
+    """Inputs of a NODEADJ_CASES entry: adjacency [B,(Ca,)N,N], node features [B,N(,Cn)], self-conditioning pair,
+    sigmas [B].  Multi-channel tensors stack independently seeded single-channel draws."""
+    N, Ca, Cn = cfg["img_size"], cfg["out_chans_adj"], cfg["out_chans_node"]
+    scale = float(np.sqrt(sigma ** 2 + 0.25))
+
+    def adj(name, sc):
+        chans = [filler.sym_adj(f"{name}{c}", B, N, flags, seed, scale=sc) for c in range(Ca)]
+        return chans[0] if Ca == 1 else torch.stack(chans, dim=1)
+
+    def node(name, sc):
+        f = filler.normalish(name, (B, N, Cn), seed) * sc * flags[:, :, None]
+        return f[..., 0].contiguous() if Cn == 1 else f
+
+    sig = torch.full((B,), float(max(sigma, 1e-3))) * (1.0 + 0.1 * filler.uniform("sig", (B,), seed)).abs()
+    return adj("adj", scale), node("node", scale), adj("sca", 0.5), node("scn", 0.5), sig
