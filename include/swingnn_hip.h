@@ -180,6 +180,44 @@ int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_pr
 int swg_mask_adjs(int32_t B, int32_t N, float* a, const float* node_flags, void* stream);
 int swg_sym_check(int32_t B, int32_t N, const float* a, float* acc, void* stream);
 
+/* ---- molecule path: node features + multi-channel adjacency ----------------------- *
+ * NodeAdjSwinGNN (model/swin_gnn/swin_gnn.py:782-1021) shares the SwinGNN trunk; `net` describes it with
+ * in_ch = (self_cond ? 2 : 1) * (Ca + 2 Cn) convolution inputs, and ro_w / ro_b unused.  Derived read-out operands:
+ *   ro       ConvTranspose2d(C0,C0,p,p) -> Conv1x1 -> Conv1x1 (:900-904, no non-linearity) collapsed to one map
+ *            [C0] -> [p*p][Cp] per token (Cp = ceil32(C0), zero rows on the padding): bf16 [p*p*Cp, Cp], bias fp32
+ *   adj_fc1 / node_fc1   readout_{adj,node}_mlp.fc1 (:913-914) as bf16 GEMM operands
+ *   *_fc2    the narrow output layers (C0 -> Ca / Cn) in fp32 */
+typedef struct swg_nodeadj {
+  int32_t Ca, Cn;
+  swg_lin ro;
+  swg_lin adj_fc1, node_fc1;
+  const float *adj_fc2_w, *adj_fc2_b;   /* [Ca, C0], [Ca] */
+  const float *node_fc2_w, *node_fc2_b; /* [Cn, C0], [Cn] */
+} swg_nodeadj;
+size_t swg_nodeadj_workspace_bytes(const swg_net* net, const swg_nodeadj* na, int32_t B);
+/* mode 1: NodeAdjPrecond.forward core, model/precond/precond.py:100-105:
+ *           (D_adj, D_node) = mask(c_skip * (adj, node) + c_out * F(c_in * adj, c_in * node, ln(sigma)/4, self-cond pair))
+ * mode 0: NodeAdjSwinGNN.forward (:960-1021), `labels` are the noise labels.
+ * adj, sc_adj, out_adj: [B, Ca, N, N]; node, sc_node, out_node: [B, N, Cn]; sc_* may be NULL (zero channels, :985-988).
+ * sym_err accumulates sum|D_adj - D_adj^T| (precond.py:106-107). */
+int swg_nodeadj_forward(const swg_net* net, const swg_nodeadj* na, int32_t B, int32_t mode, const float* adj,
+                        const float* node, const float* node_flags, const float* labels, int32_t labels_uniform,
+                        const float* sc_adj, const float* sc_node, float* out_adj, float* out_node, float* sym_err,
+                        void* ws, size_t ws_bytes, void* stream);
+/* NodeAdjEDMSampler node-feature updates (runner/mcmc_sampler/edm.py:367-426; the adjacency planes go through
+ * swg_heun_* with B*Ca planes).  x [B, N, Cn] fp32, flags [B, N]:
+ *   churn  : x_hat = mask(x + noise_coef * raw)                                  (:367-370)
+ *   euler  : d = mask((x_hat - mask(D)) / t_hat); x_prime = x_hat + h d  (masked when mask_out, :399/:426)
+ *   correct: d' = (x_prime - mask(D2)) / t_prime; x_next = mask(x_hat + h (d/2 + d'/2))      (:418-426) */
+int swg_heun_nodes_churn(int32_t B, int32_t N, int32_t Cn, const float* x, const float* raw, const float* node_flags,
+                         float noise_coef, float* x_hat, void* stream);
+int swg_heun_nodes_euler(int32_t B, int32_t N, int32_t Cn, const float* x_hat, const float* denoised,
+                         const float* node_flags, float t_hat, float h, int32_t mask_out, float* d_cur, float* x_prime,
+                         void* stream);
+int swg_heun_nodes_correct(int32_t B, int32_t N, int32_t Cn, const float* x_hat, const float* x_prime,
+                           const float* d_cur, const float* denoised2, const float* node_flags, float t_prime, float h,
+                           float* x_next, void* stream);
+
 /* ---- EDM training objective and loss, forward only ---- */
 /* runner/objectives/edm.py:160-212 (get_input_output with sigma_dist = precond = 'edm'), randn draws factored out:
  *   sigma = exp(1.2 r - 1.2), w = (sigma^2 + 1/4) / (sigma/2)^2 (:174-176), noisy = mask(clean + sigma sym(raw)),

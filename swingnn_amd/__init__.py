@@ -6,12 +6,12 @@ there is no CPU or PyTorch fallback.
 """
 from . import _lib  # noqa: F401  (fails loudly when the HIP library is absent)
 from .swin_gnn import (SwinGNN, SwinTransformerBlock, WindowAttention, PatchMerging, PatchBreakup, PatchEmbed,
-                       BasicLayer, Mlp, PositionalEmbedding)
-from .precond import Precond
-from .edm_sampler import EDMSampler, GeneralSampler
+                       BasicLayer, Mlp, PositionalEmbedding, NodeAdjSwinGNN)
+from .precond import Precond, NodeAdjPrecond
+from .edm_sampler import EDMSampler, GeneralSampler, NodeAdjEDMSampler
 from .objective import EDMObjectiveGenerator, RainbowLoss
 from .optim import FusedAdamEMA
 
 __all__ = ["SwinGNN", "SwinTransformerBlock", "WindowAttention", "PatchMerging", "PatchBreakup", "PatchEmbed",
            "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler", "EDMObjectiveGenerator", "RainbowLoss",
-           "FusedAdamEMA"]
+           "FusedAdamEMA", "NodeAdjSwinGNN", "NodeAdjPrecond", "NodeAdjEDMSampler"]

@@ -56,6 +56,11 @@ class SwgNet(C.Structure):
                 ("norm", SwgLn), ("ro_w", _fp), ("ro_b", C.c_float)]
 
 
+class SwgNodeAdj(C.Structure):
+    _fields_ = [("Ca", C.c_int32), ("Cn", C.c_int32), ("ro", SwgLin), ("adj_fc1", SwgLin), ("node_fc1", SwgLin),
+                ("adj_fc2_w", _fp), ("adj_fc2_b", _fp), ("node_fc2_w", _fp), ("node_fc2_b", _fp)]
+
+
 class SwgLinTrain(C.Structure):
     _fields_ = [("wt", _fp), ("dw", _fp), ("db", _fp)]
 
@@ -101,6 +106,12 @@ SYMBOLS = {
     "swg_heun_correct": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp]),
     "swg_mask_adjs": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
     "swg_sym_check": (C.c_int, [_i32, _i32, _fp, _fp, _fp]),
+    "swg_nodeadj_workspace_bytes": (_sz, [C.POINTER(SwgNet), C.POINTER(SwgNodeAdj), _i32]),
+    "swg_nodeadj_forward": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgNodeAdj), _i32, _i32, _fp, _fp, _fp, _fp, _i32, _fp,
+                                      _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_heun_nodes_churn": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _f, _fp, _fp]),
+    "swg_heun_nodes_euler": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _f, _f, _i32, _fp, _fp, _fp]),
+    "swg_heun_nodes_correct": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp]),
     "swg_edm_objective": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "swg_edm_loss": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _f, _i32, _fp, _fp, _fp]),
     "swg_train_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),

@@ -235,6 +235,83 @@ int plan_net(const swg_net* net, int B, NetPlan* pl) {
   return 0;
 }
 
+// persistent buffers of one pass, carved from the caller's workspace; (sw, sb) is the scratch left for the ops
+struct TrunkBufs {
+  float *coef, *cnoise, *cond, *A;
+  float* skips[8];
+  int Bc, cstride, S;
+  void* sw;
+  size_t sb;
+};
+
+int carve_trunk(const swg_net* net, int B, int labels_uniform, void* ws, size_t ws_bytes, size_t extra_scratch,
+                TrunkBufs* tb) {
+  NetPlan pl;
+  int r = plan_net(net, B, &pl);
+  if (r) return r;
+  if (ws_bytes < pl.persistent + max(pl.scratch, extra_scratch)) return SWG_E_WORKSPACE;
+  const int S = net->n_layers / 2;
+  if (S > 8) return SWG_E_UNSUPPORTED;
+  Carver cv(ws, ws_bytes);
+  tb->coef = cv.take<float>((size_t)B * 4);
+  tb->cnoise = cv.take<float>((size_t)B);
+  tb->Bc = labels_uniform ? 1 : B;
+  tb->cstride = labels_uniform ? 0 : net->cond_total;
+  tb->cond = cv.take<float>((size_t)B * net->cond_total);
+  tb->A = cv.take<float>(pl.maxTC);
+  tb->S = S;
+  for (int li = 0; li < 8; ++li) tb->skips[li] = nullptr;
+  for (int li = 0; li < S; ++li) {
+    const swg_layer& ly = net->layers[li];
+    if (ly.down) {
+      const int T = B * ly.down->res * ly.down->res;
+      tb->skips[li] = cv.take<float>((size_t)(T / 4) * 2 * ly.down->C);
+    }
+  }
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  tb->sw = cv.p;
+  tb->sb = cv.left;
+  return 0;
+}
+
+// encoder / decoder layers over the token tensor in tb.A (model/swin_gnn/swin_gnn.py:735-746); *out = final tokens
+int run_trunk(const swg_net* net, int B, const TrunkBufs& tb, const float** out, hipStream_t s) {
+  int r;
+  float* A = tb.A;
+  const int S = tb.S;
+  const float* cur = A;
+  for (int li = 0; li < net->n_layers; ++li) {
+    const swg_layer& ly = net->layers[li];
+    if (ly.up) {
+      const int si = net->n_layers - 1 - li;  // decoder layer i pops skips[S-1-i], :743
+      if (si < 0 || si >= S || !tb.skips[si]) return SWG_E_SHAPE;
+      if ((r = expand_impl(ly.up, B, cur, tb.skips[si], A, tb.sw, tb.sb, s))) return r;
+      cur = A;
+    }
+    for (int j = 0; j < ly.n_blocks; ++j) {
+      const swg_block* blk = &ly.blocks[j];
+      if ((r = wattn_impl(blk, B, cur, tb.cond, tb.cstride, A, tb.sw, tb.sb, s))) return r;
+      if ((r = mlp_impl(blk, B, A, A, tb.sw, tb.sb, s))) return r;
+      cur = A;
+    }
+    if (ly.down) {
+      if (li >= S) return SWG_E_SHAPE;
+      if ((r = merge_impl(ly.down, B, cur, tb.skips[li], tb.sw, tb.sb, s))) return r;
+      cur = tb.skips[li];
+    }
+  }
+  *out = cur;
+  return 0;
+}
+
+// scratch of the NodeAdj read-out (swg_nodeadj_forward)
+size_t ws_na_tail(const swg_net* net, const swg_nodeadj* na, int B) {
+  const int Cp = kp(net->C0), hp = net->N / net->p;
+  const size_t T = (size_t)B * hp * hp, P = (size_t)B * net->N * net->N;
+  return align256(T * Cp * 2) + 2 * align256(P * Cp * 2) + align256(P * na->Ca * 4) +
+         2 * align256((size_t)B * net->N * Cp * 2);
+}
+
 }  // namespace
 
 extern "C" {
@@ -308,58 +385,73 @@ int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float
   hipStream_t s = (hipStream_t)stream;
   if (!net || !x || !node_flags || !labels || !out) return SWG_E_NULL;
   if (B <= 0 || (mode != 0 && mode != 1)) return SWG_E_SHAPE;
-  NetPlan pl;
-  int r = plan_net(net, B, &pl);
+  TrunkBufs tb;
+  int r = carve_trunk(net, B, labels_uniform, ws, ws_bytes, 0, &tb);
   if (r) return r;
-  if (ws_bytes < pl.persistent + pl.scratch) return SWG_E_WORKSPACE;
-  const int S = net->n_layers / 2;
-  if (S > 8) return SWG_E_UNSUPPORTED;
+  if ((r = launch_edm_coef(labels, B, labels_uniform, mode, tb.coef, tb.cnoise, s))) return r;
+  if ((r = embed_impl(net, tb.Bc, tb.cnoise, tb.cond, tb.sw, tb.sb, s))) return r;
+  if ((r = launch_patch_embed(net, B, x, self_cond, tb.coef + 2, 4, tb.cond, tb.cstride, tb.A, s))) return r;
+  const float* cur = nullptr;
+  if ((r = run_trunk(net, B, tb, &cur, s))) return r;
+  return readout_impl(net, B, cur, x, node_flags, tb.coef, out, sym_err, tb.sw, tb.sb, s);
+}
 
-  Carver cv(ws, ws_bytes);
-  float* coef = cv.take<float>((size_t)B * 4);
-  float* cnoise = cv.take<float>((size_t)B);
-  const int Bc = labels_uniform ? 1 : B;
-  const int cstride = labels_uniform ? 0 : net->cond_total;
-  float* cond = cv.take<float>((size_t)B * net->cond_total);
-  float* A = cv.take<float>(pl.maxTC);
-  float* skips[8] = {};
-  for (int li = 0; li < S; ++li) {
-    const swg_layer& ly = net->layers[li];
-    if (ly.down) {
-      const int T = B * ly.down->res * ly.down->res;
-      skips[li] = cv.take<float>((size_t)(T / 4) * 2 * ly.down->C);
-    }
-  }
+size_t swg_nodeadj_workspace_bytes(const swg_net* net, const swg_nodeadj* na, int32_t B) {
+  NetPlan pl;
+  if (B <= 0 || !na || plan_net(net, B, &pl)) return 0;
+  return pl.persistent + max(pl.scratch, ws_na_tail(net, na, B)) + 4096;
+}
+
+int swg_nodeadj_forward(const swg_net* net, const swg_nodeadj* na, int32_t B, int32_t mode, const float* adj,
+                        const float* node, const float* node_flags, const float* labels, int32_t labels_uniform,
+                        const float* sc_adj, const float* sc_node, float* out_adj, float* out_node, float* sym_err,
+                        void* ws, size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!net || !na || !adj || !node || !node_flags || !labels || !out_adj || !out_node) return SWG_E_NULL;
+  if (B <= 0 || (mode != 0 && mode != 1) || na->Ca <= 0 || na->Cn <= 0 || na->Ca > 8 || na->Cn > 16) return SWG_E_SHAPE;
+  const int C0 = net->C0, Cp = kp(C0), p = net->p, pp = p * p, N = net->N;
+  int r;
+  if (C0 > 128) return SWG_E_UNSUPPORTED;
+  if (!na->adj_fc2_w || !na->adj_fc2_b || !na->node_fc2_w || !na->node_fc2_b || !na->ro.b) return SWG_E_NULL;
+  if (na->ro.N != pp * Cp || na->ro.K != C0 || na->ro.Kp != Cp || !na->ro.w) return SWG_E_SHAPE;
+  if ((r = check_lin(na->adj_fc1, C0, C0))) return r;
+  if ((r = check_lin(na->node_fc1, C0, C0))) return r;
+  TrunkBufs tb;
+  if ((r = carve_trunk(net, B, labels_uniform, ws, ws_bytes, ws_na_tail(net, na, B), &tb))) return r;
+  if ((r = launch_edm_coef(labels, B, labels_uniform, mode, tb.coef, tb.cnoise, s))) return r;
+  if ((r = embed_impl(net, tb.Bc, tb.cnoise, tb.cond, tb.sw, tb.sb, s))) return r;
+  if ((r = launch_na_embed(net, na, B, adj, node, sc_adj, sc_node, node_flags, tb.coef + 2, 4, tb.cond, tb.cstride,
+                           tb.A, s)))
+    return r;
+  const float* cur = nullptr;
+  if ((r = run_trunk(net, B, tb, &cur, s))) return r;
+
+  // read-out (:953-956) and the two MLP heads (:1000-1012)
+  const int hp = N / p, T = B * hp * hp, P = T * pp;  // P = B N N pixels, rows in token-patch order
+  Carver cv(tb.sw, tb.sb);
+  bf16* xn = cv.take<bf16>((size_t)T * Cp);
+  bf16* rep = cv.take<bf16>((size_t)P * Cp);
+  bf16* hid = cv.take<bf16>((size_t)P * Cp);
+  float* F = cv.take<float>((size_t)B * na->Ca * N * N);
+  bf16* pooled = cv.take<bf16>((size_t)B * N * Cp);
+  bf16* hidn = cv.take<bf16>((size_t)B * N * Cp);
   if (!cv.ok) return SWG_E_WORKSPACE;
-  void* sw = cv.p;
-  const size_t sb = cv.left;
-
-  if ((r = launch_edm_coef(labels, B, labels_uniform, mode, coef, cnoise, s))) return r;
-  if ((r = embed_impl(net, Bc, cnoise, cond, sw, sb, s))) return r;
-  if ((r = launch_patch_embed(net, B, x, self_cond, coef + 2, 4, cond, cstride, A, s))) return r;
-
-  const float* cur = A;
-  for (int li = 0; li < net->n_layers; ++li) {
-    const swg_layer& ly = net->layers[li];
-    if (ly.up) {
-      const int si = net->n_layers - 1 - li;  // decoder layer i pops skips[S-1-i], :743
-      if (si < 0 || si >= S || !skips[si]) return SWG_E_SHAPE;
-      if ((r = expand_impl(ly.up, B, cur, skips[si], A, sw, sb, s))) return r;
-      cur = A;
-    }
-    for (int j = 0; j < ly.n_blocks; ++j) {
-      const swg_block* blk = &ly.blocks[j];
-      if ((r = wattn_impl(blk, B, cur, cond, cstride, A, sw, sb, s))) return r;
-      if ((r = mlp_impl(blk, B, A, A, sw, sb, s))) return r;
-      cur = A;
-    }
-    if (ly.down) {
-      if (li >= S) return SWG_E_SHAPE;
-      if ((r = merge_impl(ly.down, B, cur, skips[li], sw, sb, s))) return r;
-      cur = skips[li];
-    }
-  }
-  return readout_impl(net, B, cur, x, node_flags, coef, out, sym_err, sw, sb, s);
+  if ((r = launch_cond_ln(cur, T, C0, hp * hp, nullptr, 0, 0, net->norm.g, net->norm.b, nullptr, xn, Cp, s))) return r;
+  GemmEpi e = {};
+  e.bias = na->ro.b; e.out_bf16 = rep; e.ldo = pp * Cp; e.n_store = pp * Cp;
+  if ((r = launch_gemm(xn, Cp, (const bf16*)na->ro.w, T, pp * Cp, Cp, e, s))) return r;
+  GemmEpi e1 = {};
+  e1.bias = na->adj_fc1.b; e1.act = 1; e1.out_bf16 = hid; e1.ldo = Cp; e1.n_store = Cp;
+  if ((r = launch_gemm(rep, Cp, (const bf16*)na->adj_fc1.w, P, C0, Cp, e1, s))) return r;
+  if ((r = launch_na_head_adj(hid, Cp, B, N, p, C0, na->Ca, na->adj_fc2_w, na->adj_fc2_b, F, s))) return r;
+  const float* coef = mode ? tb.coef : nullptr;
+  if ((r = launch_sym_precond_ch(B, na->Ca, N, F, mode ? adj : nullptr, node_flags, coef, out_adj, sym_err, s))) return r;
+  if ((r = launch_na_pool(rep, Cp, B, N, p, node_flags, pooled, s))) return r;
+  GemmEpi e2 = {};
+  e2.bias = na->node_fc1.b; e2.act = 1; e2.out_bf16 = hidn; e2.ldo = Cp; e2.n_store = Cp;
+  if ((r = launch_gemm(pooled, Cp, (const bf16*)na->node_fc1.w, B * N, C0, Cp, e2, s))) return r;
+  return launch_na_head_node(hidn, Cp, B, N, C0, na->Cn, na->node_fc2_w, na->node_fc2_b, node, node_flags, coef,
+                             out_node, s);
 }
 
 }  // extern "C"

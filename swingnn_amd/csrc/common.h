@@ -146,6 +146,17 @@ int launch_patch_embed(const swg_net* net, int B, const float* x, const float* s
 int launch_final_readout(const swg_net* net, int B, const float* tok, float* F, hipStream_t s);
 int launch_sym_precond(int B, int N, const float* F, const float* x, const float* flags, const float* coef, float* out,
                        float* sym_err, hipStream_t s);
+int launch_sym_precond_ch(int B, int Ca, int N, const float* F, const float* x, const float* flags, const float* coef,
+                          float* out, float* sym_err, hipStream_t s);
+// nodeadj.hip : head and tail of the molecule (node + adjacency) network, model/swin_gnn/swin_gnn.py:960-1021
+int launch_na_embed(const swg_net* net, const swg_nodeadj* na, int B, const float* adj, const float* node,
+                    const float* sc_adj, const float* sc_node, const float* flags, const float* c_in, int c_in_stride,
+                    const float* cond, int cond_stride, float* tok, hipStream_t s);
+int launch_na_head_adj(const bf16* h, int ldh, int B, int N, int p, int C, int Ca, const float* w2, const float* b2,
+                       float* F, hipStream_t s);
+int launch_na_head_node(const bf16* h, int ldh, int B, int N, int C, int Cn, const float* w2, const float* b2,
+                        const float* node, const float* flags, const float* coef, float* out, hipStream_t s);
+int launch_na_pool(const bf16* rep, int ldr, int B, int N, int p, const float* flags, bf16* pooled, hipStream_t s);
 // gemm.hip : out[M,N] = A[M,Kp] @ W[N,Kp]^T (+bias)(gelu)(+residual)
 struct GemmEpi {
   const float* bias;      // [N] or null

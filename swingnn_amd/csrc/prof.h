@@ -28,6 +28,7 @@ enum SwgKernelId {
   KID_BWD_ROWS,
   KID_WATTN_BWD,
   KID_OPTIM,
+  KID_NODEADJ,
   KID_COUNT
 };
 

@@ -28,7 +28,8 @@ const char* kNames[KID_COUNT] = {"k_gemm_nt",      "k_wattn_core",  "k_row<cond_
                                  "k_pos_embed",    "k_edm_coef",    "k_patch_embed",  "k_final_readout",
                                  "k_sym_precond",  "k_heun",        "k_wattn_fused",  "k_mlp_fused",
                                  "k_mlp_stream",   "k_wattn_ring",  "k_wattn_res",    "k_breakup_post",
-                                 "bwd_rows",       "k_wattn_bwd",   "k_adam_ema"};
+                                 "bwd_rows",       "k_wattn_bwd",   "k_adam_ema",
+                                 "k_nodeadj"};
 
 void drain() {  // caller holds the lock; synchronises the recorded events
   for (size_t i = 0; i < P.used; ++i) {

@@ -621,16 +621,18 @@ __device__ __forceinline__ float block_sum_256(float v, float* red) {
 }
 
 // out = mask(c_skip*x + c_out*0.5*(Fm + Fm^T)), Fm = mask(F): swin_gnn.py:777-778, precond.py:49-51
-__global__ __launch_bounds__(256) void k_sym_precond(int N, const float* __restrict__ F, const float* __restrict__ x,
-                                                     const float* __restrict__ flags, const float* __restrict__ coef,
-                                                     float* __restrict__ out, float* __restrict__ sym_err) {
+// Ca: adjacency channels per graph (planes [B*Ca, N, N]; flags / coef are per graph) -- 1 for SwinGNN
+__global__ __launch_bounds__(256) void k_sym_precond(int N, int Ca, const float* __restrict__ F,
+                                                     const float* __restrict__ x, const float* __restrict__ flags,
+                                                     const float* __restrict__ coef, float* __restrict__ out,
+                                                     float* __restrict__ sym_err) {
   __shared__ float tF[32][33];
   __shared__ float tX[32][33];
   __shared__ float red[4];
-  const int bi = blockIdx.z;
+  const int bi = blockIdx.z / Ca;
   const int r0 = blockIdx.y * 32, c0 = blockIdx.x * 32;
   const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;
-  const size_t base = (size_t)bi * N * N;
+  const size_t base = (size_t)blockIdx.z * N * N;
   const float c_skip = coef ? coef[4 * bi + 0] : 0.f;
   const float c_out = coef ? coef[4 * bi + 1] : 1.f;
   // transposed tile: rows c0.., cols r0..
@@ -664,13 +666,18 @@ __global__ __launch_bounds__(256) void k_sym_precond(int N, const float* __restr
   }
 }
 
-int launch_sym_precond(int B, int N, const float* F, const float* x, const float* flags, const float* coef, float* out,
-                       float* sym_err, hipStream_t s) {
-  dim3 grid(cdiv(N, 32), cdiv(N, 32), B);
-  SwgProfScope ps(KID_SYM_PRECOND, 0.0, 4.0 * B * (double)N * N * (x ? 3 : 2), s);
-  hipLaunchKernelGGL(k_sym_precond, grid, dim3(256), 0, s, N, F, x, flags, coef, out, sym_err);
+int launch_sym_precond_ch(int B, int Ca, int N, const float* F, const float* x, const float* flags, const float* coef,
+                          float* out, float* sym_err, hipStream_t s) {
+  dim3 grid(cdiv(N, 32), cdiv(N, 32), B * Ca);
+  SwgProfScope ps(KID_SYM_PRECOND, 0.0, 4.0 * B * Ca * (double)N * N * (x ? 3 : 2), s);
+  hipLaunchKernelGGL(k_sym_precond, grid, dim3(256), 0, s, N, Ca, F, x, flags, coef, out, sym_err);
   SWG_LAUNCH_CHECK();
   return 0;
+}
+
+int launch_sym_precond(int B, int N, const float* F, const float* x, const float* flags, const float* coef, float* out,
+                       float* sym_err, hipStream_t s) {
+  return launch_sym_precond_ch(B, 1, N, F, x, flags, coef, out, sym_err, s);
 }
 
 // x_hat = mask(x + coef * sym(raw)); sym(raw)[r][c] = raw[min][max] off the diagonal, 0 on it.

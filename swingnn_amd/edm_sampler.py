@@ -168,3 +168,140 @@ class EDMSampler(GeneralSampler):
         if flag_interim_adjs:
             return adjs, torch.stack(adjs_ls)
         return adjs
+
+
+class NodeAdjEDMSampler(EDMSampler):
+    """Drop-in for the molecule sampler (reference runner/mcmc_sampler/edm.py:235-449): nodes and (multi-channel)
+    adjacency matrices are integrated together.  The adjacency planes [B,Ca,N,N] go through the same swg_heun_*
+    kernels as B*Ca graphs (flags repeated per plane), the node features [B,N,Cn] through swg_heun_nodes_*.  As in the
+    reference the adjacency noise is drawn before the node noise each step (:362-368)."""
+
+    def __init__(self, *, sigma_min=None, sigma_max=None, solver='heun', discretization='edm', schedule='linear',
+                 scaling='none', C_1=0.001, C_2=0.008, M=1000, alpha=1,
+                 num_steps=256, S_churn=40, S_min=0.05, S_max=50, S_noise=1.003,
+                 clip_samples, clip_samples_min, clip_samples_max, clip_samples_scope,
+                 self_condition, dev, objective='edm', symmetric_noise=True):
+        super().__init__(sigma_min=sigma_min, sigma_max=sigma_max, solver=solver, discretization=discretization,
+                         schedule=schedule, scaling=scaling, C_1=C_1, C_2=C_2, M=M, alpha=alpha, num_steps=num_steps,
+                         S_churn=S_churn, S_min=S_min, S_max=S_max, S_noise=S_noise, clip_samples=clip_samples,
+                         clip_samples_min=clip_samples_min, clip_samples_max=clip_samples_max,
+                         clip_samples_scope=clip_samples_scope, self_condition=self_condition, dev=dev,
+                         objective=objective)
+        if not symmetric_noise:
+            raise NotImplementedError("swingnn_amd.NodeAdjEDMSampler: symmetric_noise=True (the shipped setting)")
+        self.symmetric_noise = symmetric_noise
+
+    def gen_init_sample(self, node_flags, folded_norm=False, flag_node_multi_channel=False,
+                        flag_adj_multi_channel=False, num_node_chan=150, num_edge_chan=51):
+        """(:261-293) both draws on the CPU generator, adjacency first."""
+        B, N = node_flags.shape[:2]
+        raw = torch.randn((B, num_edge_chan, N, N)).triu(diagonal=1).to(self.dev)
+        raw = raw.abs() if folded_norm else raw
+        init_adjs = (raw + raw.transpose(-1, -2)).contiguous()
+        flags = E._as_f32(node_flags.to(init_adjs.device))
+        rep = flags.repeat_interleave(num_edge_chan, dim=0).contiguous()
+        L.check(L.lib.swg_mask_adjs(B * num_edge_chan, N, init_adjs.data_ptr(), rep.data_ptr(), E.stream_ptr()),
+                "swg_mask_adjs")
+        if num_edge_chan == 1:
+            init_adjs = init_adjs.squeeze(1)
+        init_nodes = torch.randn((B, N, num_node_chan)).to(self.dev)
+        zero = torch.zeros_like(init_nodes)
+        L.check(L.lib.swg_heun_nodes_churn(B, N, num_node_chan, init_nodes.data_ptr(), zero.data_ptr(), flags.data_ptr(),
+                                           0.0, init_nodes.data_ptr(), E.stream_ptr()), "swg_heun_nodes_churn")
+        if num_node_chan == 1:
+            init_nodes = init_nodes.squeeze(-1)
+        return init_adjs, init_nodes
+
+    def sample(self, model, node_flags, init_adjs=None, init_nodes=None, sanity_check_gt_adjs=None,
+               sanity_check_gt_nodes=None, flag_interim_adjs=False, max_num_interim_adjs=None, flag_use_double=False,
+               flag_node_multi_channel=False, flag_adj_multi_channel=False, num_node_chan=150, num_edge_chan=51):
+        if flag_use_double:
+            raise NotImplementedError("swingnn_amd.NodeAdjEDMSampler keeps the Heun state in float32")
+        inner = model.module if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else model
+        if init_adjs is None or init_nodes is None:
+            init_adjs, init_nodes = self.gen_init_sample(node_flags, folded_norm=False, num_node_chan=num_node_chan,
+                                                         num_edge_chan=num_edge_chan)
+        dev = init_adjs.device
+        if dev.type != 'cuda':
+            raise RuntimeError("swingnn_amd.NodeAdjEDMSampler needs the state on an MI355X (got %s); no CPU fallback" % dev)
+        flags = E._as_f32(node_flags.to(dev))
+        B, N = flags.shape
+        adj_shape, node_shape = init_adjs.shape, init_nodes.shape
+        Ca = 1 if init_adjs.dim() == 3 else adj_shape[1]
+        Cn = 1 if init_nodes.dim() == 2 else node_shape[2]
+        BA = B * Ca
+        flags_a = flags.repeat_interleave(Ca, dim=0).contiguous() if Ca > 1 else flags
+        adjs_ls, nodes_ls = ([init_adjs.cpu()], [init_nodes.cpu()]) if flag_interim_adjs else ([], [])
+        if max_num_interim_adjs is None:
+            snaps = set(range(self.num_steps))
+        else:
+            snaps = set(np.linspace(0, self.num_steps, max_num_interim_adjs).astype(int)
+                        .clip(max=self.num_steps - 1).tolist())
+        consts = self.step_constants()
+        sym_acc = torch.zeros(1, dtype=torch.float32, device=dev)
+        gta = None if sanity_check_gt_adjs is None else E._as_f32(sanity_check_gt_adjs.to(dev))
+        gtn = None if sanity_check_gt_nodes is None else E._as_f32(sanity_check_gt_nodes.to(dev))
+        debug = logging.getLogger().isEnabledFor(logging.DEBUG)
+        lib, sp = L.lib, E.stream_ptr
+        t0 = float(self.sigma_steps[0].to(torch.float32))
+        a_next = (E._as_f32(init_adjs) * t0).contiguous()
+        n_next = (E._as_f32(init_nodes) * t0).contiguous()
+        a_hat, a_prime, da_cur = torch.empty_like(a_next), torch.empty_like(a_next), torch.empty_like(a_next)
+        n_hat, n_prime, dn_cur = torch.empty_like(n_next), torch.empty_like(n_next), torch.empty_like(n_next)
+        sc_a = sc_n = None
+        fp = flags.data_ptr()
+        fap = flags_a.data_ptr()
+        for i, (t_hat, coef, h, t_prime) in enumerate(consts):
+            raw_a = self._randn_like(a_next)
+            raw_n = self._randn_like(n_next)
+            L.check(lib.swg_heun_churn(BA, N, a_next.data_ptr(), raw_a.data_ptr(), fap, coef, a_hat.data_ptr(), sp()),
+                    "swg_heun_churn")
+            L.check(lib.swg_heun_nodes_churn(B, N, Cn, n_next.data_ptr(), raw_n.data_ptr(), fp, coef, n_hat.data_ptr(),
+                                             sp()), "swg_heun_nodes_churn")
+            sig = torch.full((1,), t_hat, dtype=torch.float32, device=dev).expand(B)
+            if gta is None:
+                with torch.no_grad():
+                    den_a, den_n = model(a_hat, n_hat, flags, sig, sc_a, sc_n)
+                den_a, den_n = E._as_f32(den_a), E._as_f32(den_n)
+            else:
+                den_a, den_n = gta, gtn
+            last = self.solver == 'euler' or i == self.num_steps - 1
+            a_new, n_new = torch.empty_like(a_hat), torch.empty_like(n_hat)
+            L.check(lib.swg_heun_euler(BA, N, a_hat.data_ptr(), den_a.data_ptr(), fap, t_hat, h, int(last),
+                                       da_cur.data_ptr(), (a_new if last else a_prime).data_ptr(), sp()),
+                    "swg_heun_euler")
+            L.check(lib.swg_heun_nodes_euler(B, N, Cn, n_hat.data_ptr(), den_n.data_ptr(), fp, t_hat, h, int(last),
+                                             dn_cur.data_ptr(), (n_new if last else n_prime).data_ptr(), sp()),
+                    "swg_heun_nodes_euler")
+            if not last:
+                if gta is None:
+                    sc_n = den_n if self.self_condition else None
+                    sc_a = den_a if self.self_condition else None
+                    with torch.no_grad():
+                        den_a, den_n = model(a_hat, n_hat, flags, sig, sc_a, sc_n)  # (x_hat, t_hat) again, :404-409
+                    den_a, den_n = E._as_f32(den_a), E._as_f32(den_n)
+                L.check(lib.swg_heun_correct(BA, N, a_hat.data_ptr(), a_prime.data_ptr(), da_cur.data_ptr(),
+                                             den_a.data_ptr(), fap, t_prime, h, a_new.data_ptr(), sp()),
+                        "swg_heun_correct")
+                L.check(lib.swg_heun_nodes_correct(B, N, Cn, n_hat.data_ptr(), n_prime.data_ptr(), dn_cur.data_ptr(),
+                                                   den_n.data_ptr(), fp, t_prime, h, n_new.data_ptr(), sp()),
+                        "swg_heun_nodes_correct")
+            a_next, n_next = a_new, n_new
+            sc_a = den_a if self.self_condition else None
+            sc_n = den_n if self.self_condition else None
+            L.check(lib.swg_sym_check(BA, N, a_next.data_ptr(), sym_acc.data_ptr(), sp()), "swg_sym_check")
+            if flag_interim_adjs and i in snaps:
+                adjs_ls.append(a_next.cpu())
+                nodes_ls.append(n_next.cpu())
+            if debug:
+                logging.debug("EDM-NodeAdj MCMC: step {:5d} | avg. #edges@0.0 of x_t: {:08d} |".format(
+                    i, int(EDMSampler.get_num_edges(a_next, flags if Ca == 1 else flags[:, None], 0.0).mean().item())))
+        adjs, nodes = a_next.cpu(), n_next.cpu()
+        assert float(sym_acc.item()) < 1e-2, "sampler state lost symmetry"
+        if hasattr(inner, 'assert_symmetric'):
+            inner.assert_symmetric()
+        if flag_interim_adjs:
+            if flag_adj_multi_channel:
+                return adjs, nodes, [None], torch.stack(nodes_ls)
+            return adjs, nodes, torch.stack(adjs_ls), torch.stack(nodes_ls)
+        return adjs, nodes

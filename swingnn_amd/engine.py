@@ -222,6 +222,36 @@ def collapse_read_out(read_out, p: int):
     return weff.float().contiguous(), float(beff)
 
 
+def collapse_read_out_nodeadj(read_out, p: int):
+    """NodeAdjSwinGNN read-out (model/swin_gnn/swin_gnn.py:900-904): ConvTranspose2d(C,C,p,p) -> Conv1x1(C,C) ->
+    Conv1x1(C,C) with no non-linearity = one affine map [C] -> [p*p, C] per token.  float64 on device.
+    Returns (W [p*p, C_out, C_in], b [C_out])."""
+    W0 = read_out[0].weight.detach().double()              # [Cin, C0, p, p]
+    W1 = read_out[1].weight.detach().double()[:, :, 0, 0]  # [C1, C0]
+    W2 = read_out[2].weight.detach().double()[:, :, 0, 0]  # [C2, C1]
+    M = W2 @ W1                                            # [C2, C0]
+    weff = torch.einsum("oc,icyx->yxoi", M, W0).reshape(p * p, M.shape[0], W0.shape[0])
+    beff = M @ read_out[0].bias.detach().double() + W2 @ read_out[1].bias.detach().double() \
+        + read_out[2].bias.detach().double()
+    return weff, beff
+
+
+def nodeadj_desc(keep: Keep, model, p: int) -> L.SwgNodeAdj:
+    C0 = model.embed_dim
+    Cp = _kp(C0)
+    weff, beff = collapse_read_out_nodeadj(model.read_out, p)
+    wb = torch.zeros((p * p, Cp, Cp), dtype=torch.bfloat16, device=weff.device)
+    wb[:, :C0, :C0] = weff
+    bb = torch.zeros((p * p, Cp), dtype=torch.float32, device=weff.device)
+    bb[:, :C0] = beff.float()
+    keep(wb), keep(bb)
+    ro = L.SwgLin(_ptr(wb), _ptr(bb), p * p * Cp, C0, Cp)
+    am, nm = model.readout_adj_mlp, model.readout_node_mlp
+    return L.SwgNodeAdj(model.out_chans_adj, model.out_chans_node, ro,
+                        keep.lin(am.fc1.weight, am.fc1.bias), keep.lin(nm.fc1.weight, nm.fc1.bias),
+                        keep.f32(am.fc2.weight), keep.f32(am.fc2.bias), keep.f32(nm.fc2.weight), keep.f32(nm.fc2.bias))
+
+
 class NetCache:
     """Descriptor + derived weights of one SwinGNN module on one device."""
 
@@ -260,8 +290,13 @@ class NetCache:
         freqs = torch.arange(0, half, dtype=torch.float32, device=dev) / half
         freqs = keep(((1 / 10000) ** freqs).contiguous())  # PositionalEmbedding, swin_gnn.py:508-510
         p = model.patch_embed.patch_size[0]
-        ro_w, ro_b = collapse_read_out(model.read_out, p)
-        keep(ro_w)
+        self.nodeadj = None
+        if hasattr(model, "readout_adj_mlp"):  # NodeAdjSwinGNN: C0 -> C0 read-out + two MLP heads
+            ro_w, ro_b = None, 0.0
+            self.nodeadj = keep(nodeadj_desc(keep, model, p))
+        else:
+            ro_w, ro_b = collapse_read_out(model.read_out, p)
+            keep(ro_w)
         pe = model.patch_embed
         pe_w = keep(_f32(pe.proj.weight).reshape(C0, -1).contiguous())
         self.net = L.SwgNet(
@@ -276,7 +311,10 @@ class NetCache:
     def ws_bytes(self, B: int) -> int:
         n = self._ws_bytes.get(B)
         if n is None:
-            n = int(L.lib.swg_workspace_bytes(C.byref(self.net), B))
+            if self.nodeadj is not None:
+                n = int(L.lib.swg_nodeadj_workspace_bytes(C.byref(self.net), C.byref(self.nodeadj), B))
+            else:
+                n = int(L.lib.swg_workspace_bytes(C.byref(self.net), B))
             if n == 0:
                 raise L.SwgError("swg_workspace_bytes: unsupported network geometry")
             self._ws_bytes[B] = n
@@ -323,3 +361,30 @@ def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
                                       int(labels_uniform), _ptr(sc), out.data_ptr(), _ptr(sym_err), ws.data_ptr(),
                                       ws.numel(), stream_ptr()), "swg_precond_forward")
     return out
+
+
+def nodeadj_pass(cache: NetCache, mode: int, adj, node, node_flags, labels, labels_uniform: bool, sc_adj, sc_node,
+                 sym_err=None):
+    """One pass of the molecule network through swg_nodeadj_forward (mode 0: NodeAdjSwinGNN.forward, mode 1:
+    NodeAdjPrecond core).  adj [B,Ca,N,N], node [B,N,Cn] (already in the library's layout) -> (adj_out, node_out)."""
+    na = cache.nodeadj
+    adj, node = _as_f32(adj), _as_f32(node)
+    flags = _as_f32(node_flags)
+    labels = _as_f32(labels)
+    sc_adj = None if sc_adj is None else _as_f32(sc_adj)
+    sc_node = None if sc_node is None else _as_f32(sc_node)
+    B, N = adj.shape[0], adj.shape[-1]
+    if adj.dim() != 4 or adj.shape[1] != na.Ca or adj.shape[2] != N or N != cache.net.N:
+        raise AssertionError(f"Input image size ({adj.shape[-2]}*{N}) doesn't match model ({cache.net.N}*{cache.net.N}).")
+    if tuple(node.shape) != (B, N, na.Cn):
+        raise AssertionError(f"node features {tuple(node.shape)} do not match [B, N, {na.Cn}]")
+    for t, ref in ((sc_adj, adj), (sc_node, node)):
+        if t is not None and t.shape != ref.shape:
+            raise AssertionError("self-conditioning tensors must have the shapes of the inputs")
+    out_adj, out_node = torch.empty_like(adj), torch.empty_like(node)
+    ws = workspace(adj.device, cache.ws_bytes(B))
+    L.check(L.lib.swg_nodeadj_forward(C.byref(cache.net), C.byref(na), B, mode, adj.data_ptr(), node.data_ptr(),
+                                      flags.data_ptr(), labels.data_ptr(), int(labels_uniform), _ptr(sc_adj),
+                                      _ptr(sc_node), out_adj.data_ptr(), out_node.data_ptr(), _ptr(sym_err),
+                                      ws.data_ptr(), ws.numel(), stream_ptr()), "swg_nodeadj_forward")
+    return out_adj, out_node

@@ -68,3 +68,49 @@ class Precond(nn.Module):
     @staticmethod
     def round_sigma(sigma):
         return torch.as_tensor(sigma)
+
+
+class NodeAdjPrecond(Precond):
+    """Drop-in for the molecule preconditioner (reference model/precond/precond.py:60-114):
+    ``forward(adjs, nodes, node_flags, sigmas, self_cond_adjs=None, self_cond_nodes=None) -> (D_adjs, D_nodes)``.
+    Unlike ``Precond`` the passed self-conditioning tensors are used (:81-82) unless the numpy coin (:90) replaces
+    them with a fresh no-grad pass."""
+
+    def __init__(self, precond, model, self_condition, symmetric_noise=True):
+        from .swin_gnn import NodeAdjSwinGNN
+        nn.Module.__init__(self)
+        assert precond in ['vp', 've', 'edm']
+        if precond != 'edm':
+            raise NotImplementedError("swingnn_amd.NodeAdjPrecond implements precond='edm'")
+        if not isinstance(model, NodeAdjSwinGNN):
+            raise TypeError("swingnn_amd.NodeAdjPrecond wraps swingnn_amd.NodeAdjSwinGNN")
+        if not symmetric_noise:
+            raise NotImplementedError("swingnn_amd.NodeAdjPrecond: symmetric_noise=True (utils/learning_utils.py:149)")
+        self.precond, self.model, self.self_condition = precond, model, self_condition
+        self.symmetric_noise = symmetric_noise
+        self.symmetry_check = 'deferred'
+        self._sym_acc = None
+
+    def forward(self, adjs, nodes=None, node_flags=None, sigmas=None, self_cond_adjs=None, self_cond_nodes=None,
+                *args, **model_kwargs):
+        m = self.model
+        if torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
+            raise NotImplementedError("swingnn_amd.NodeAdjPrecond: training backward of the molecule path is not built "
+                                      "yet; call under torch.no_grad()")
+        sigmas = torch.as_tensor(sigmas, device=adjs.device).reshape(-1)
+        uniform = sigmas.numel() == 1 or (sigmas.dim() == 1 and sigmas.stride(0) == 0)
+        if not uniform and sigmas.numel() != adjs.shape[0]:
+            raise AssertionError("sigmas must have one entry per sample")
+        labels = sigmas[:1] if uniform else sigmas
+        cache = E.get_cache(m)
+        a, n = m._adj_in(adjs), m._node_in(nodes.to(torch.float32))
+        sa, sn = m._adj_in(self_cond_adjs), m._node_in(self_cond_nodes)
+        if self.self_condition and np.random.rand() < 0.5:
+            sa, sn = E.nodeadj_pass(cache, 1, a, n, node_flags, labels, uniform,
+                                    sa if m.self_condition else None, sn if m.self_condition else None)
+        acc = None if self.symmetry_check == 'off' else self._acc(adjs.device)
+        Da, Dn = E.nodeadj_pass(cache, 1, a, n, node_flags, labels, uniform, sa if m.self_condition else None,
+                                sn if m.self_condition else None, sym_err=acc)
+        if self.symmetry_check == 'eager':
+            self.assert_symmetric()
+        return m._adj_out(Da), m._node_out(Dn)

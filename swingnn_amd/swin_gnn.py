@@ -347,3 +347,105 @@ class SwinGNN(nn.Module):
             from .train import denoise_with_grad
             return denoise_with_grad(self, 0, x, node_flags, labels, self_cond)
         return E.network_pass(cache, 0, x, node_flags, labels, False, self_cond)
+
+
+class NodeAdjSwinGNN(nn.Module):
+    """Swin-UNet denoiser on node features + (multi-channel) adjacency matrices: the molecule model of the reference
+    (model/swin_gnn/swin_gnn.py:782-1021), same constructor keywords, ``forward`` signature and ``state_dict`` keys,
+    executed by swg_nodeadj_forward.  ``in_chans`` = 2 * node channels + adjacency channels
+    (utils/learning_utils.py:184-214), doubled internally under self-conditioning (:825-826)."""
+
+    def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 6, 2],
+                 num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None,
+                 drop_rate=0., attn_drop_rate=0., drop_path_rate=0.1, out_chans_adj=1, out_chans_node=1,
+                 norm_layer=nn.LayerNorm, patch_norm=True, use_checkpoint=False, self_condition=False,
+                 symmetric_noise=True, **kwargs):
+        super().__init__()
+        if drop_rate or attn_drop_rate or drop_path_rate:
+            raise NotImplementedError("swingnn_amd: dropout / stochastic depth must be 0 (utils/learning_utils.py:116)")
+        if not symmetric_noise:
+            raise NotImplementedError("swingnn_amd.NodeAdjSwinGNN: symmetric_noise=True (utils/learning_utils.py:119)")
+        if in_chans != 2 * out_chans_node + out_chans_adj:
+            raise NotImplementedError("swingnn_amd.NodeAdjSwinGNN: in_chans must be 2*out_chans_node + out_chans_adj "
+                                      "(utils/learning_utils.py:203-212)")
+        self.num_layers = len(depths)
+        self.embed_dim, self.patch_norm = embed_dim, patch_norm
+        self.num_features = int(embed_dim * 2 ** (self.num_layers - 1))
+        self.mlp_ratio = mlp_ratio
+        self.self_condition = self_condition
+        in_chans = in_chans * 2 if self_condition else in_chans
+        self.symmetric_noise = symmetric_noise
+        self.out_chans_adj, self.out_chans_node = out_chans_adj, out_chans_node
+        self.patch_embed = PatchEmbed(img_size=img_size, patch_size=patch_size, in_chans=in_chans, embed_dim=embed_dim,
+                                      noise_emb_channels=NOISE_EMB, norm_layer=norm_layer if patch_norm else None)
+        pr = self.patches_resolution = self.patch_embed.patches_resolution
+        self.pos_drop = nn.Dropout(p=drop_rate)
+        S = self.num_layers
+        common = dict(noise_emb_channels=NOISE_EMB, window_size=window_size, mlp_ratio=mlp_ratio, qkv_bias=qkv_bias,
+                      qk_scale=qk_scale, drop=drop_rate, attn_drop=attn_drop_rate, drop_path=0., norm_layer=norm_layer,
+                      use_checkpoint=use_checkpoint)
+        self.down_layers = nn.ModuleList()
+        for i in range(S):
+            self.down_layers.append(BasicLayer(dim=int(embed_dim * 2 ** i),
+                                               input_resolution=(pr[0] // 2 ** i, pr[1] // 2 ** i), depth=depths[i],
+                                               num_heads=num_heads[i],
+                                               downsample=PatchMerging if i < S - 1 else None, upsample=None, **common))
+        self.up_layers = nn.ModuleList()
+        for i in range(S):
+            rest = S - i - 1
+            k = rest if i == 0 else rest + 1
+            self.up_layers.append(BasicLayer(dim=int(embed_dim * 2 ** rest),
+                                             input_resolution=(pr[0] // 2 ** k, pr[1] // 2 ** k), depth=depths[rest],
+                                             num_heads=num_heads[rest], downsample=None,
+                                             upsample=PatchBreakup if i > 0 else None, **common))
+        self.read_out = nn.Sequential(
+            nn.ConvTranspose2d(embed_dim, embed_dim, kernel_size=patch_size, stride=patch_size),
+            nn.Conv2d(embed_dim, embed_dim, kernel_size=1, stride=1, padding=0),
+            nn.Conv2d(embed_dim, embed_dim, kernel_size=1, stride=1, padding=0))
+        self.map_noise = PositionalEmbedding(num_channels=embed_dim)
+        self.map_layer0 = nn.Linear(in_features=embed_dim, out_features=NOISE_EMB)
+        self.map_layer1 = nn.Linear(in_features=NOISE_EMB, out_features=NOISE_EMB)
+        self.norm = norm_layer(self.embed_dim)
+        self.readout_adj_mlp = Mlp(in_features=embed_dim, hidden_features=embed_dim, out_features=out_chans_adj)
+        self.readout_node_mlp = Mlp(in_features=embed_dim, hidden_features=embed_dim, out_features=out_chans_node)
+        self.apply(self._init_weights)
+
+    _init_weights = SwinGNN._init_weights
+
+    @torch.jit.ignore
+    def no_weight_decay(self):
+        return {'absolute_pos_embed'}
+
+    @torch.jit.ignore
+    def no_weight_decay_keywords(self):
+        return {'relative_position_bias_table'}
+
+    # layout between the reference's tensors and the library's [B,Ca,N,N] / [B,N,Cn]
+    def _adj_in(self, t):
+        return None if t is None else (t.unsqueeze(1) if t.dim() == 3 else t)
+
+    def _node_in(self, t):
+        return None if t is None else (t.unsqueeze(-1) if t.dim() == 2 else t)
+
+    def _adj_out(self, t):
+        return t.squeeze(1) if self.out_chans_adj == 1 else t
+
+    def _node_out(self, t):
+        return t.squeeze(-1) if self.out_chans_node == 1 else t
+
+    def forward(self, adj, node, node_flags, noise_labels, self_cond_x=None, self_cond_feat=None):
+        """adj [B,N,N] | [B,Ca,N,N], node [B,N] | [B,N,Cn], node_flags [B,N], noise_labels [B] -> (adj_out, node_out)
+        in the layouts of the inputs (reference :960-1021)."""
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            raise NotImplementedError("swingnn_amd.NodeAdjSwinGNN: the training backward of the molecule head / tail is "
+                                      "not built yet; call under torch.no_grad()")
+        if not self.self_condition:
+            self_cond_x = self_cond_feat = None
+        cache = E.get_cache(self)
+        a = self._adj_in(adj)
+        labels = noise_labels.reshape(-1)
+        if labels.numel() == 1 and a.shape[0] != 1:
+            labels = labels.expand(a.shape[0])
+        oa, on = E.nodeadj_pass(cache, 0, a, self._node_in(node.to(torch.float32)), node_flags, labels, False,
+                                self._adj_in(self_cond_x), self._node_in(self_cond_feat))
+        return self._adj_out(oa), self._node_out(on)

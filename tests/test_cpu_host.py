@@ -163,3 +163,56 @@ def test_collapsed_read_out_weights(S, golden_meta):
     w, b = E.collapse_read_out(pre.model.read_out, 4)
     w_ref, b_ref = O.collapsed_read_out(O._strip(sd), 4)
     assert torch.allclose(w.double(), w_ref, atol=1e-7) and abs(b - float(b_ref)) < 1e-6
+
+
+# ---- molecule path (NodeAdjSwinGNN / NodeAdjPrecond), host side ---------------------------------------------
+def build_nodeadj(S, cfg):
+    net = S.NodeAdjSwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=cfg["in_chans"],
+                           embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                           window_size=cfg["window_size"], mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                           drop_path_rate=0.0, self_condition=cfg["self_condition"], symmetric_noise=True,
+                           out_chans_adj=cfg["out_chans_adj"], out_chans_node=cfg["out_chans_node"])
+    return S.NodeAdjPrecond("edm", net, cfg["self_condition"], symmetric_noise=True)
+
+
+def test_nodeadj_state_dict_contract_and_seeded_init(S, golden_nodeadj):
+    from tests.golden.cases import NODEADJ_CASES
+    g, meta = golden_nodeadj
+    for name, c in NODEADJ_CASES.items():
+        pre = build_nodeadj(S, c["cfg"])
+        sd = pre.state_dict()
+        ref = meta[f"keys/{name}"]
+        assert set(sd) == set(ref), name
+        for k, v in sd.items():
+            assert list(v.shape) == ref[k][0] and str(v.dtype) == ref[k][1], k
+        assert sum(p.numel() for p in pre.parameters()) == meta[f"nparams/{name}"]
+    torch.manual_seed(1234)
+    sd = build_nodeadj(S, NODEADJ_CASES["qm9_onehot96"]["cfg"]).state_dict()
+    keys = meta["init_keys/qm9_onehot96"]
+    sums = np.array([float(sd[k].double().sum()) for k in keys])
+    asums = np.array([float(sd[k].double().abs().sum()) for k in keys])
+    assert np.allclose(sums, g["nainit/qm9_onehot96/sums"], rtol=0, atol=1e-9)
+    assert np.allclose(asums, g["nainit/qm9_onehot96/abs_sums"], rtol=1e-12)
+
+
+def test_nodeadj_collapsed_read_out(S, golden_nodeadj):
+    """The three read-out convolutions as one [C] -> [p*p, C] map: equal to running them (float64)."""
+    import torch.nn.functional as F
+    from swingnn_amd import engine as E
+    from tests import helpers as H
+    from tests.golden.cases import NODEADJ_CASES
+    _, meta = golden_nodeadj
+    cfg = NODEADJ_CASES["zinc_ddpm96"]["cfg"]
+    pre = build_nodeadj(S, cfg)
+    sd = H.net_state(meta["keys/zinc_ddpm96"], 5, "stress")
+    pre.load_state_dict({k: v for k, v in sd.items() if torch.is_floating_point(v) and not k.endswith("attn_mask")},
+                        strict=False)
+    p, C0 = cfg["patch_size"], cfg["embed_dim"]
+    w, b = E.collapse_read_out_nodeadj(pre.model.read_out, p)          # [p*p, Cout, Cin], [Cout]
+    x = torch.randn(2, C0, 3, 3, dtype=torch.float64)
+    ro = pre.model.read_out
+    y = F.conv_transpose2d(x, ro[0].weight.double(), ro[0].bias.double(), stride=p)
+    y = F.conv2d(F.conv2d(y, ro[1].weight.double(), ro[1].bias.double()), ro[2].weight.double(), ro[2].bias.double())
+    mine = torch.einsum("koi,biyx->bykxo", w, x) + b                   # [B, Y, k = i*p+j, X, Cout]
+    mine = mine.reshape(2, 3, p, p, 3, C0).permute(0, 5, 1, 2, 4, 3).reshape(2, C0, 3 * p, 3 * p)
+    assert torch.allclose(mine, y, atol=1e-9)
