@@ -308,6 +308,49 @@ int swg_edm_loss_bwd(int32_t B, int32_t N, const float* pred, const float* targe
                      const float* weights, const float* grad_loss, float regression_loss_weight, float* grad_pred,
                      void* stream);
 
+/* ---- training step of the molecule path (runner/trainer/trainer_node_adj.py:95-131) ----------------------- *
+ * Op-level forward halves of swg_nodeadj_forward (the trunk between them goes through swg_wattn_fwd, ... above), their
+ * backward passes, and the node-feature halves of NodeAdjEDMObjectiveGenerator / NodeAdjRainbowLoss (the adjacency
+ * halves are swg_edm_objective / swg_edm_loss over the B*Ca planes). */
+typedef struct swg_nodeadj_train {
+  const void* ro_wt;            /* bf16 [C0, p*p*Cp]: the collapsed read-out map transposed (dxn = drep Wro)        */
+  float* dro_w;                 /* fp32 [p*p*Cp, C0] gradient of the collapsed map (caller chains it to read_out.*)  */
+  float* dro_b;                 /* fp32 [p*p*Cp]                                                                      */
+  swg_lin_train adj_fc1, node_fc1;
+  float *dadj_fc2_w, *dadj_fc2_b;   /* [Ca, C0], [Ca] */
+  float *dnode_fc2_w, *dnode_fc2_b; /* [Cn, C0], [Cn] */
+  swg_ln_train norm;
+} swg_nodeadj_train;
+size_t swg_nodeadj_train_workspace_bytes(const swg_net* net, const swg_nodeadj* na, int32_t B);
+/* input planes (:985-996, c_in of precond.py:100) + PatchEmbed (:562-577) -> tok [B, L, C0] */
+int swg_nodeadj_embed_fwd(const swg_net* net, const swg_nodeadj* na, int32_t B, const float* adj, const float* node,
+                          const float* sc_adj, const float* sc_node, const float* node_flags, const float* c_in,
+                          int32_t c_in_stride, const float* cond, int32_t cond_stride, float* tok, void* stream);
+/* final norm + read_out (:953-956) + MLP heads + pooling + masks / symmetrisation (:1000-1018) + precond epilogue
+ * (precond.py:102-105; coef [B,4] or NULL = NodeAdjSwinGNN.forward) */
+int swg_nodeadj_readout_fwd(const swg_net* net, const swg_nodeadj* na, int32_t B, const float* tok, const float* adj,
+                            const float* node, const float* node_flags, const float* coef, float* out_adj,
+                            float* out_node, float* sym_err, void* ws, size_t ws_bytes, void* stream);
+/* d swg_nodeadj_embed_fwd w.r.t. its parameters and the conditioning row (inputs are data) */
+int swg_nodeadj_embed_bwd(const swg_net* net, const swg_nodeadj* na, const swg_ends_train* tr, int32_t B,
+                          const float* adj, const float* node, const float* sc_adj, const float* sc_node,
+                          const float* node_flags, const float* c_in, int32_t c_in_stride, const float* cond,
+                          int32_t cond_stride, const float* dtok, float* dcond, int32_t dcond_stride, void* ws,
+                          size_t ws_bytes, void* stream);
+/* d swg_nodeadj_readout_fwd: (d_adj [B,Ca,N,N], d_node [B,N,Cn]) -> dtok [B,L,C0] + parameter gradients */
+int swg_nodeadj_readout_bwd(const swg_net* net, const swg_nodeadj* na, const swg_nodeadj_train* tr, int32_t B,
+                            const float* tok, const float* node_flags, const float* coef, const float* d_adj,
+                            const float* d_node, float* dtok, void* ws, size_t ws_bytes, void* stream);
+/* runner/objectives/edm.py:243-247: noisy = clean + mask(sigma_b * raw), x [B, N, Cn] */
+int swg_nodes_objective(int32_t B, int32_t N, int32_t Cn, const float* clean, const float* raw_noise,
+                        const float* node_flags, const float* sigmas, float* noisy, void* stream);
+/* loss/rainbow_loss.py:211-248 (reduction 'none'): loss_b = w_b sum flag (pred - target)^2 / sum(flags_b) / Cn * weight */
+int swg_nodes_loss(int32_t B, int32_t N, int32_t Cn, const float* pred, const float* target, const float* node_flags,
+                   const float* weights, float node_loss_weight, float* loss, void* stream);
+int swg_nodes_loss_bwd(int32_t B, int32_t N, int32_t Cn, const float* pred, const float* target, const float* node_flags,
+                       const float* weights, const float* grad_loss, float node_loss_weight, float* grad_pred,
+                       void* stream);
+
 /* ---- optimizer tail of the train step (runner/trainer/trainer.py:136-140) ---------------- *
  * Multi-tensor kernels over all parameters.  p_ptrs / g_ptrs: DEVICE arrays of n_tensors fp32 pointers (the
  * nn.Parameters and their .grad); numel [n_tensors] int32; flat_off [n_tensors] int64 = offset of the tensor inside

@@ -9,9 +9,9 @@ from .swin_gnn import (SwinGNN, SwinTransformerBlock, WindowAttention, PatchMerg
                        BasicLayer, Mlp, PositionalEmbedding, NodeAdjSwinGNN)
 from .precond import Precond, NodeAdjPrecond
 from .edm_sampler import EDMSampler, GeneralSampler, NodeAdjEDMSampler
-from .objective import EDMObjectiveGenerator, RainbowLoss
+from .objective import EDMObjectiveGenerator, RainbowLoss, NodeAdjEDMObjectiveGenerator, NodeAdjRainbowLoss
 from .optim import FusedAdamEMA
 
 __all__ = ["SwinGNN", "SwinTransformerBlock", "WindowAttention", "PatchMerging", "PatchBreakup", "PatchEmbed",
            "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler", "EDMObjectiveGenerator", "RainbowLoss",
-           "FusedAdamEMA", "NodeAdjSwinGNN", "NodeAdjPrecond", "NodeAdjEDMSampler"]
+           "FusedAdamEMA", "NodeAdjSwinGNN", "NodeAdjPrecond", "NodeAdjEDMSampler", "NodeAdjEDMObjectiveGenerator", "NodeAdjRainbowLoss"]

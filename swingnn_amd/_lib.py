@@ -87,6 +87,12 @@ class SwgEndsTrain(C.Structure):
                 ("ro_wb", _fp), ("dro_w", _fp), ("dro_b", _fp)]
 
 
+class SwgNodeAdjTrain(C.Structure):
+    _fields_ = [("ro_wt", _fp), ("dro_w", _fp), ("dro_b", _fp), ("adj_fc1", SwgLinTrain), ("node_fc1", SwgLinTrain),
+                ("dadj_fc2_w", _fp), ("dadj_fc2_b", _fp), ("dnode_fc2_w", _fp), ("dnode_fc2_b", _fp),
+                ("norm", SwgLnTrain)]
+
+
 # every symbol include/swingnn_hip.h declares: name -> (restype, argtypes)
 _i32, _sz, _f = C.c_int32, C.c_size_t, C.c_float
 SYMBOLS = {
@@ -127,6 +133,18 @@ SYMBOLS = {
     "swg_readout_sym_precond_bwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgEndsTrain), _i32, _fp, _fp, _fp, _fp, _fp,
                                               _fp, _sz, _fp]),
     "swg_edm_loss_bwd": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _fp, _fp]),
+    "swg_nodeadj_train_workspace_bytes": (_sz, [C.POINTER(SwgNet), C.POINTER(SwgNodeAdj), _i32]),
+    "swg_nodeadj_embed_fwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgNodeAdj), _i32, _fp, _fp, _fp, _fp, _fp, _fp, _i32,
+                                        _fp, _i32, _fp, _fp]),
+    "swg_nodeadj_readout_fwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgNodeAdj), _i32, _fp, _fp, _fp, _fp, _fp, _fp,
+                                          _fp, _fp, _fp, _sz, _fp]),
+    "swg_nodeadj_embed_bwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgNodeAdj), C.POINTER(SwgEndsTrain), _i32, _fp, _fp,
+                                        _fp, _fp, _fp, _fp, _i32, _fp, _i32, _fp, _fp, _i32, _fp, _sz, _fp]),
+    "swg_nodeadj_readout_bwd": (C.c_int, [C.POINTER(SwgNet), C.POINTER(SwgNodeAdj), C.POINTER(SwgNodeAdjTrain), _i32, _fp,
+                                          _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_nodes_objective": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "swg_nodes_loss": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _fp, _f, _fp, _fp]),
+    "swg_nodes_loss_bwd": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _fp, _fp]),
     "swg_optim_chunk": (C.c_int, []),
     "swg_grad_sqnorm": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _fp, _fp]),
     "swg_adam_ema_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _fp, _fp, _fp, C.c_int64, _i32,

@@ -312,6 +312,51 @@ size_t ws_na_tail(const swg_net* net, const swg_nodeadj* na, int B) {
          2 * align256((size_t)B * net->N * Cp * 2);
 }
 
+// NodeAdjSwinGNN read-out (:953-956), the two MLP heads (:1000-1012), masks / symmetrisation (:1015-1018) and the
+// preconditioning epilogue (precond.py:102-105) on the final tokens `cur`
+int na_readout_impl(const swg_net* net, const swg_nodeadj* na, int B, int mode, const float* cur, const float* adj,
+                    const float* node, const float* node_flags, const float* coef, float* out_adj, float* out_node,
+                    float* sym_err, void* ws, size_t ws_bytes, hipStream_t s) {
+  const int C0 = net->C0, Cp = kp(C0), p = net->p, pp = p * p, N = net->N;
+  int r;
+  const int hp = N / p, T = B * hp * hp, P = T * pp;  // P = B N N pixels, rows in token-patch order
+  Carver cv(ws, ws_bytes);
+  bf16* xn = cv.take<bf16>((size_t)T * Cp);
+  bf16* rep = cv.take<bf16>((size_t)P * Cp);
+  bf16* hid = cv.take<bf16>((size_t)P * Cp);
+  float* F = cv.take<float>((size_t)B * na->Ca * N * N);
+  bf16* pooled = cv.take<bf16>((size_t)B * N * Cp);
+  bf16* hidn = cv.take<bf16>((size_t)B * N * Cp);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  if ((r = launch_cond_ln(cur, T, C0, hp * hp, nullptr, 0, 0, net->norm.g, net->norm.b, nullptr, xn, Cp, s))) return r;
+  GemmEpi e = {};
+  e.bias = na->ro.b; e.out_bf16 = rep; e.ldo = pp * Cp; e.n_store = pp * Cp;
+  if ((r = launch_gemm(xn, Cp, (const bf16*)na->ro.w, T, pp * Cp, Cp, e, s))) return r;
+  GemmEpi e1 = {};
+  e1.bias = na->adj_fc1.b; e1.act = 1; e1.out_bf16 = hid; e1.ldo = Cp; e1.n_store = Cp;
+  if ((r = launch_gemm(rep, Cp, (const bf16*)na->adj_fc1.w, P, C0, Cp, e1, s))) return r;
+  if ((r = launch_na_head_adj(hid, Cp, B, N, p, C0, na->Ca, na->adj_fc2_w, na->adj_fc2_b, F, s))) return r;
+  if ((r = launch_sym_precond_ch(B, na->Ca, N, F, coef ? adj : nullptr, node_flags, coef, out_adj, sym_err, s))) return r;
+  if ((r = launch_na_pool(rep, Cp, B, N, p, node_flags, pooled, s))) return r;
+  GemmEpi e2 = {};
+  e2.bias = na->node_fc1.b; e2.act = 1; e2.out_bf16 = hidn; e2.ldo = Cp; e2.n_store = Cp;
+  if ((r = launch_gemm(pooled, Cp, (const bf16*)na->node_fc1.w, B * N, C0, Cp, e2, s))) return r;
+  return launch_na_head_node(hidn, Cp, B, N, C0, na->Cn, na->node_fc2_w, na->node_fc2_b, node, node_flags, coef,
+                             out_node, s);
+}
+
+int check_nodeadj(const swg_net* net, const swg_nodeadj* na) {
+  if (!net || !na) return SWG_E_NULL;
+  if (na->Ca <= 0 || na->Cn <= 0 || na->Ca > 8 || na->Cn > 16) return SWG_E_SHAPE;
+  const int C0 = net->C0, Cp = kp(C0), pp = net->p * net->p;
+  if (C0 > 128) return SWG_E_UNSUPPORTED;
+  if (!na->adj_fc2_w || !na->adj_fc2_b || !na->node_fc2_w || !na->node_fc2_b || !na->ro.b) return SWG_E_NULL;
+  if (na->ro.N != pp * Cp || na->ro.K != C0 || na->ro.Kp != Cp || !na->ro.w) return SWG_E_SHAPE;
+  int r;
+  if ((r = check_lin(na->adj_fc1, C0, C0))) return r;
+  return check_lin(na->node_fc1, C0, C0);
+}
+
 }  // namespace
 
 extern "C" {
@@ -408,14 +453,9 @@ int swg_nodeadj_forward(const swg_net* net, const swg_nodeadj* na, int32_t B, in
                         void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!net || !na || !adj || !node || !node_flags || !labels || !out_adj || !out_node) return SWG_E_NULL;
-  if (B <= 0 || (mode != 0 && mode != 1) || na->Ca <= 0 || na->Cn <= 0 || na->Ca > 8 || na->Cn > 16) return SWG_E_SHAPE;
-  const int C0 = net->C0, Cp = kp(C0), p = net->p, pp = p * p, N = net->N;
+  if (B <= 0 || (mode != 0 && mode != 1)) return SWG_E_SHAPE;
   int r;
-  if (C0 > 128) return SWG_E_UNSUPPORTED;
-  if (!na->adj_fc2_w || !na->adj_fc2_b || !na->node_fc2_w || !na->node_fc2_b || !na->ro.b) return SWG_E_NULL;
-  if (na->ro.N != pp * Cp || na->ro.K != C0 || na->ro.Kp != Cp || !na->ro.w) return SWG_E_SHAPE;
-  if ((r = check_lin(na->adj_fc1, C0, C0))) return r;
-  if ((r = check_lin(na->node_fc1, C0, C0))) return r;
+  if ((r = check_nodeadj(net, na))) return r;
   TrunkBufs tb;
   if ((r = carve_trunk(net, B, labels_uniform, ws, ws_bytes, ws_na_tail(net, na, B), &tb))) return r;
   if ((r = launch_edm_coef(labels, B, labels_uniform, mode, tb.coef, tb.cnoise, s))) return r;
@@ -426,32 +466,31 @@ int swg_nodeadj_forward(const swg_net* net, const swg_nodeadj* na, int32_t B, in
   const float* cur = nullptr;
   if ((r = run_trunk(net, B, tb, &cur, s))) return r;
 
-  // read-out (:953-956) and the two MLP heads (:1000-1012)
-  const int hp = N / p, T = B * hp * hp, P = T * pp;  // P = B N N pixels, rows in token-patch order
-  Carver cv(tb.sw, tb.sb);
-  bf16* xn = cv.take<bf16>((size_t)T * Cp);
-  bf16* rep = cv.take<bf16>((size_t)P * Cp);
-  bf16* hid = cv.take<bf16>((size_t)P * Cp);
-  float* F = cv.take<float>((size_t)B * na->Ca * N * N);
-  bf16* pooled = cv.take<bf16>((size_t)B * N * Cp);
-  bf16* hidn = cv.take<bf16>((size_t)B * N * Cp);
-  if (!cv.ok) return SWG_E_WORKSPACE;
-  if ((r = launch_cond_ln(cur, T, C0, hp * hp, nullptr, 0, 0, net->norm.g, net->norm.b, nullptr, xn, Cp, s))) return r;
-  GemmEpi e = {};
-  e.bias = na->ro.b; e.out_bf16 = rep; e.ldo = pp * Cp; e.n_store = pp * Cp;
-  if ((r = launch_gemm(xn, Cp, (const bf16*)na->ro.w, T, pp * Cp, Cp, e, s))) return r;
-  GemmEpi e1 = {};
-  e1.bias = na->adj_fc1.b; e1.act = 1; e1.out_bf16 = hid; e1.ldo = Cp; e1.n_store = Cp;
-  if ((r = launch_gemm(rep, Cp, (const bf16*)na->adj_fc1.w, P, C0, Cp, e1, s))) return r;
-  if ((r = launch_na_head_adj(hid, Cp, B, N, p, C0, na->Ca, na->adj_fc2_w, na->adj_fc2_b, F, s))) return r;
-  const float* coef = mode ? tb.coef : nullptr;
-  if ((r = launch_sym_precond_ch(B, na->Ca, N, F, mode ? adj : nullptr, node_flags, coef, out_adj, sym_err, s))) return r;
-  if ((r = launch_na_pool(rep, Cp, B, N, p, node_flags, pooled, s))) return r;
-  GemmEpi e2 = {};
-  e2.bias = na->node_fc1.b; e2.act = 1; e2.out_bf16 = hidn; e2.ldo = Cp; e2.n_store = Cp;
-  if ((r = launch_gemm(pooled, Cp, (const bf16*)na->node_fc1.w, B * N, C0, Cp, e2, s))) return r;
-  return launch_na_head_node(hidn, Cp, B, N, C0, na->Cn, na->node_fc2_w, na->node_fc2_b, node, node_flags, coef,
-                             out_node, s);
+  return na_readout_impl(net, na, B, mode, cur, adj, node, node_flags, mode ? tb.coef : nullptr, out_adj, out_node, sym_err,
+                         tb.sw, tb.sb, s);
+}
+
+int swg_nodeadj_embed_fwd(const swg_net* net, const swg_nodeadj* na, int32_t B, const float* adj, const float* node,
+                          const float* sc_adj, const float* sc_node, const float* node_flags, const float* c_in,
+                          int32_t c_in_stride, const float* cond, int32_t cond_stride, float* tok, void* stream) {
+  if (!net || !na || !adj || !node || !node_flags || !cond || !tok || !net->pe_w || !net->pe_b || !net->pe_ln.g ||
+      !net->pe_ln.b)
+    return SWG_E_NULL;
+  if (B <= 0) return SWG_E_SHAPE;
+  return launch_na_embed(net, na, B, adj, node, sc_adj, sc_node, node_flags, c_in, c_in_stride, cond, cond_stride, tok,
+                         (hipStream_t)stream);
+}
+
+int swg_nodeadj_readout_fwd(const swg_net* net, const swg_nodeadj* na, int32_t B, const float* tok, const float* adj,
+                            const float* node, const float* node_flags, const float* coef, float* out_adj,
+                            float* out_node, float* sym_err, void* ws, size_t ws_bytes, void* stream) {
+  if (!tok || !node_flags || !out_adj || !out_node || (coef && (!adj || !node))) return SWG_E_NULL;
+  if (B <= 0) return SWG_E_SHAPE;
+  int r;
+  if ((r = check_nodeadj(net, na))) return r;
+  if (!net->norm.g || !net->norm.b) return SWG_E_NULL;
+  return na_readout_impl(net, na, B, coef ? 1 : 0, tok, adj, node, node_flags, coef, out_adj, out_node, sym_err, ws,
+                         ws_bytes, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -273,6 +273,119 @@ int readout_bwd_impl(const swg_net* net, const swg_ends_train* tr, int B, const 
   return launch_ln_bwd(tok, dtn, net->norm.g, nullptr, T, C0, dtok, tr->norm.dg, tr->norm.db, s);
 }
 
+// ---- molecule path (NodeAdjSwinGNN head / tail, model/swin_gnn/swin_gnn.py:953-1018) -------------------------
+int na_embed_bwd_impl(const swg_net* net, const swg_nodeadj* na, const swg_ends_train* tr, int B, const float* adj,
+                      const float* node, const float* sc_adj, const float* sc_node, const float* flags, const float* c_in,
+                      int c_in_stride, const float* cond, int cond_stride, const float* dtok, float* dcond,
+                      int dcond_stride, Carver& cv, hipStream_t s) {
+  const int hp = net->N / net->p, L = hp * hp, T = B * L, C0 = net->C0, kin = net->in_ch * net->p * net->p, Kp = kp(kin);
+  bf16* P = cv.take<bf16>((size_t)T * Kp);
+  float* u = cv.take<float>((size_t)T * C0);
+  float* un = cv.take<float>((size_t)T * C0);
+  float* dun = cv.take<float>((size_t)T * C0);
+  float* tmp = cv.take<float>((size_t)C0 * Kp);
+  WgradScratch w = take_wgrad(cv, C0, Kp, T);
+  if (cv.measure) return 0;
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  if (!tr->pe_wb || !tr->dpe_w || !tr->dpe_b || !tr->pe_ln.dg || !tr->pe_ln.db) return SWG_E_NULL;
+  int r;
+  if ((r = launch_na_im2col(net, na, B, adj, node, sc_adj, sc_node, flags, c_in, c_in_stride, P, Kp, s))) return r;
+  GemmEpi e = {};
+  e.bias = net->pe_b; e.out_f32 = u; e.ldo = C0;
+  if ((r = launch_gemm(P, Kp, (const bf16*)tr->pe_wb, T, C0, Kp, e, s))) return r;
+  if ((r = launch_ln_f32(u, T, C0, net->pe_ln.g, net->pe_ln.b, un, s))) return r;
+  if ((r = launch_cond_bwd(un, dtok, cond, cond_stride, net->pe_cond_off, B, L, C0, dun, dcond, dcond_stride, s))) return r;
+  if ((r = launch_ln_bwd(u, dun, net->pe_ln.g, nullptr, T, C0, dun, tr->pe_ln.dg, tr->pe_ln.db, s))) return r;
+  hipError_t he = hipMemsetAsync(tmp, 0, (size_t)C0 * Kp * sizeof(float), s);
+  if (he != hipSuccess) return (int)he;
+  if ((r = wgrad(dun, nullptr, C0, C0, P, Kp, Kp, T, tmp, w, s))) return r;
+  if ((r = launch_add_slice(tmp, C0, kin, Kp, tr->dpe_w, s))) return r;
+  return launch_colsum_f32(dun, T, C0, C0, tr->dpe_b, s);
+}
+
+// one read-out MLP head backwards: rows of `in` (bf16 [rows, Cp]) -> fc1 -> GELU -> fc2 (Co outputs, fp32 weights).
+// dy fp32 [rows, Co]; writes din fp32 [rows, C0] (+= when `accumulate`), accumulates the four parameter gradients.
+int na_head_bwd(const swg_lin& fc1, const swg_lin_train& t1, const float* w2, float* dw2, float* db2, int Co,
+                const bf16* in, const float* dy, int rows, int C0, bf16* pre, bf16* act, float* din, bool accumulate,
+                const WgradScratch& w, hipStream_t s) {
+  const int Cp = kp(C0);
+  int r;
+  GemmEpi e = {};
+  e.bias = fc1.b; e.out_bf16 = pre; e.ldo = Cp; e.n_store = Cp;
+  if ((r = launch_gemm(in, Cp, (const bf16*)fc1.w, rows, C0, Cp, e, s))) return r;
+  if ((r = launch_gelu_fwd(pre, act, (size_t)rows * Cp, s))) return r;
+  // fc2: dW2 += dy^T act, db2 += colsum(dy), dact = dy W2
+  if ((r = wgrad(dy, nullptr, Co, Co, act, Cp, C0, rows, dw2, w, s))) return r;
+  if ((r = launch_colsum_f32(dy, rows, Co, Co, db2, s))) return r;
+  if ((r = launch_na_head_bwd(dy, w2, rows, C0, Co, act, Cp, s))) return r;   // act now holds d(act)
+  if ((r = launch_gelu_bwd(pre, act, act, (size_t)rows * Cp, s))) return r;   // ... and now d(pre)
+  GemmEpi e2 = {};
+  e2.out_f32 = din; e2.ldo = C0;
+  if (accumulate) { e2.residual = din; e2.ldr = C0; }
+  if ((r = launch_gemm(act, Cp, (const bf16*)t1.wt, rows, C0, Cp, e2, s))) return r;
+  if ((r = wgrad(nullptr, act, Cp, C0, in, Cp, C0, rows, t1.dw, w, s))) return r;
+  return launch_colsum_bf16(act, rows, C0, Cp, t1.db, s);
+}
+
+int na_readout_bwd_impl(const swg_net* net, const swg_nodeadj* na, const swg_nodeadj_train* tr, int B, const float* tok,
+                        const float* flags, const float* coef, const float* dDa, const float* dDn, float* dtok,
+                        Carver& cv, hipStream_t s) {
+  const int N = net->N, p = net->p, pp = p * p, hp = N / p, L = hp * hp, T = B * L, P = T * pp, C0 = net->C0, Cp = kp(C0);
+  const int Ca = na ? na->Ca : 8, Cn = na ? na->Cn : 16, BN = B * N;
+  bf16* xn = cv.take<bf16>((size_t)T * Cp);
+  bf16* rep = cv.take<bf16>((size_t)P * Cp);
+  bf16* pre = cv.take<bf16>((size_t)P * Cp);
+  bf16* act = cv.take<bf16>((size_t)P * Cp);
+  bf16* pooled = cv.take<bf16>((size_t)BN * Cp);
+  float* dya = cv.take<float>((size_t)P * Ca);
+  float* dyn = cv.take<float>((size_t)BN * Cn);
+  float* dpooled = cv.take<float>((size_t)BN * C0);
+  float* drep = cv.take<float>((size_t)P * C0);
+  bf16* drepb = cv.take<bf16>((size_t)P * Cp);
+  float* dxn = cv.take<float>((size_t)T * C0);
+  // weight-gradient scratch shared by the heads (Co | C0 rows x P) and the read-out map (pp Cp rows x T)
+  WgradScratch w;
+  {
+    const size_t cols = (size_t)round_up(P, 32) + (size_t)32 * pp;  // >= pp * round_up(T, 32)
+    w.tA = cv.take<bf16>((size_t)Cp * cols);
+    w.tB = cv.take<bf16>((size_t)Cp * cols);
+    w.partial_floats = gemm_splitk_ws_floats(pp * Cp, Cp);
+    w.partial = cv.take<float>(w.partial_floats);
+  }
+  if (cv.measure) return 0;
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  int r;
+  if ((r = check_lin_train(tr->adj_fc1, true)) || (r = check_lin_train(tr->node_fc1, true))) return r;
+  if (!tr->ro_wt || !tr->dro_w || !tr->dro_b || !tr->dadj_fc2_w || !tr->dadj_fc2_b || !tr->dnode_fc2_w ||
+      !tr->dnode_fc2_b || !tr->norm.dg || !tr->norm.db)
+    return SWG_E_NULL;
+  // ---- recompute (:953-956, :1006-1007) ----
+  if ((r = launch_cond_ln(tok, T, C0, L, nullptr, 0, 0, net->norm.g, net->norm.b, nullptr, xn, Cp, s))) return r;
+  GemmEpi e = {};
+  e.bias = na->ro.b; e.out_bf16 = rep; e.ldo = pp * Cp; e.n_store = pp * Cp;
+  if ((r = launch_gemm(xn, Cp, (const bf16*)na->ro.w, T, pp * Cp, Cp, e, s))) return r;
+  if ((r = launch_na_pool(rep, Cp, B, N, p, flags, pooled, s))) return r;
+  // ---- node head (:1009-1015, precond.py:103-105), then the pooling ----
+  if ((r = launch_na_dnode(dDn, flags, coef, B, N, Cn, dyn, s))) return r;
+  if ((r = na_head_bwd(na->node_fc1, tr->node_fc1, na->node_fc2_w, tr->dnode_fc2_w, tr->dnode_fc2_b, Cn, pooled, dyn, BN,
+                       C0, pre, act, dpooled, false, w, s)))
+    return r;
+  if ((r = launch_na_pool_bwd(dpooled, flags, B, N, p, C0, drep, s))) return r;
+  // ---- adjacency head (:1000-1003, :1016-1018, precond.py:102-104): accumulates into drep ----
+  if ((r = launch_na_dadj(dDa, flags, coef, B, N, p, Ca, dya, s))) return r;
+  if ((r = na_head_bwd(na->adj_fc1, tr->adj_fc1, na->adj_fc2_w, tr->dadj_fc2_w, tr->dadj_fc2_b, Ca, rep, dya, P, C0, pre,
+                       act, drep, true, w, s)))
+    return r;
+  // ---- collapsed read-out: rep[t, (ij, c')] = xn[t] . Wro[(ij, c'), :] + b ----
+  if ((r = launch_cast_pad(drep, P, C0, C0, drepb, Cp, s))) return r;
+  GemmEpi e2 = {};
+  e2.out_f32 = dxn; e2.ldo = C0;
+  if ((r = launch_gemm(drepb, pp * Cp, (const bf16*)tr->ro_wt, T, C0, pp * Cp, e2, s))) return r;
+  if ((r = wgrad(nullptr, drepb, pp * Cp, pp * Cp, xn, Cp, C0, T, tr->dro_w, w, s))) return r;
+  if ((r = launch_colsum_bf16(drepb, T, pp * Cp, pp * Cp, tr->dro_b, s))) return r;
+  return launch_ln_bwd(tok, dxn, net->norm.g, nullptr, T, C0, dtok, tr->norm.dg, tr->norm.db, s);
+}
+
 }  // namespace
 
 extern "C" {
@@ -372,6 +485,45 @@ int swg_readout_sym_precond_bwd(const swg_net* net, const swg_ends_train* tr, in
   if (B <= 0 || net->C0 % 4) return SWG_E_SHAPE;
   Carver cv(ws, ws_bytes);
   return readout_bwd_impl(net, tr, B, tok, node_flags, coef, dD, dtok, cv, (hipStream_t)stream);
+}
+
+size_t swg_nodeadj_train_workspace_bytes(const swg_net* net, const swg_nodeadj* na, int32_t B) {
+  size_t need = swg_train_workspace_bytes(net, B);
+  if (!need || !na) return 0;
+  {
+    Carver cv;
+    na_embed_bwd_impl(net, na, nullptr, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr,
+                      nullptr, 0, cv, nullptr);
+    need = max(need, cv.used + 4096);
+  }
+  {
+    Carver cv;
+    na_readout_bwd_impl(net, na, nullptr, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cv, nullptr);
+    need = max(need, cv.used + 4096);
+  }
+  return need;
+}
+
+int swg_nodeadj_embed_bwd(const swg_net* net, const swg_nodeadj* na, const swg_ends_train* tr, int32_t B,
+                          const float* adj, const float* node, const float* sc_adj, const float* sc_node,
+                          const float* node_flags, const float* c_in, int32_t c_in_stride, const float* cond,
+                          int32_t cond_stride, const float* dtok, float* dcond, int32_t dcond_stride, void* ws,
+                          size_t ws_bytes, void* stream) {
+  if (!net || !na || !tr || !adj || !node || !node_flags || !cond || !dtok || !dcond) return SWG_E_NULL;
+  if (B <= 0 || net->C0 % 4) return SWG_E_SHAPE;
+  if (cond_stride <= 0) return SWG_E_UNSUPPORTED;
+  Carver cv(ws, ws_bytes);
+  return na_embed_bwd_impl(net, na, tr, B, adj, node, sc_adj, sc_node, node_flags, c_in, c_in_stride, cond, cond_stride,
+                           dtok, dcond, dcond_stride, cv, (hipStream_t)stream);
+}
+
+int swg_nodeadj_readout_bwd(const swg_net* net, const swg_nodeadj* na, const swg_nodeadj_train* tr, int32_t B,
+                            const float* tok, const float* node_flags, const float* coef, const float* d_adj,
+                            const float* d_node, float* dtok, void* ws, size_t ws_bytes, void* stream) {
+  if (!net || !na || !tr || !tok || !node_flags || !d_adj || !d_node || !dtok) return SWG_E_NULL;
+  if (B <= 0 || net->C0 % 4 || net->C0 > 128 || na->Ca <= 0 || na->Ca > 8 || na->Cn <= 0 || na->Cn > 16) return SWG_E_SHAPE;
+  Carver cv(ws, ws_bytes);
+  return na_readout_bwd_impl(net, na, tr, B, tok, node_flags, coef, d_adj, d_node, dtok, cv, (hipStream_t)stream);
 }
 
 }  // extern "C"

@@ -157,6 +157,15 @@ int launch_na_head_adj(const bf16* h, int ldh, int B, int N, int p, int C, int C
 int launch_na_head_node(const bf16* h, int ldh, int B, int N, int C, int Cn, const float* w2, const float* b2,
                         const float* node, const float* flags, const float* coef, float* out, hipStream_t s);
 int launch_na_pool(const bf16* rep, int ldr, int B, int N, int p, const float* flags, bf16* pooled, hipStream_t s);
+int launch_na_im2col(const swg_net* net, const swg_nodeadj* na, int B, const float* adj, const float* node,
+                     const float* sc_adj, const float* sc_node, const float* flags, const float* c_in, int c_in_stride,
+                     bf16* out, int Kp, hipStream_t s);
+int launch_na_dadj(const float* dD, const float* flags, const float* coef, int B, int N, int p, int Ca, float* dy,
+                   hipStream_t s);
+int launch_na_dnode(const float* dD, const float* flags, const float* coef, int B, int N, int Cn, float* dy,
+                    hipStream_t s);
+int launch_na_head_bwd(const float* dy, const float* w2, int rows, int C, int Co, bf16* dact, int ld, hipStream_t s);
+int launch_na_pool_bwd(const float* dpooled, const float* flags, int B, int N, int p, int C, float* drep, hipStream_t s);
 // gemm.hip : out[M,N] = A[M,Kp] @ W[N,Kp]^T (+bias)(gelu)(+residual)
 struct GemmEpi {
   const float* bias;      // [N] or null

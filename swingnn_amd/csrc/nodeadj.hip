@@ -22,6 +22,48 @@ struct NaEmbedArgs {
   int B, N, p, in_ch, C, G, Ca, Cn;
 };
 
+// value of convolution input channel ci at pixel (r, c) of graph bi (channel order above)
+__device__ __forceinline__ float na_input_value(const NaEmbedArgs& a, int bi, int ci, int r, int c) {
+  const int nA = a.G * a.Ca, nF = a.G * a.Cn;
+  const float cin = a.c_in ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f;
+  if (ci < nA) {
+    const bool is_sc = a.G == 2 && ci < a.Ca;
+    const int ch = is_sc ? ci : ci - (a.G - 1) * a.Ca;
+    const size_t off = (((size_t)bi * a.Ca + ch) * a.N + r) * a.N + c;
+    if (is_sc) return a.sc_adj ? a.sc_adj[off] : 0.f;
+    return cin * a.adj[off];
+  }
+  const int cf = ci - nA;
+  const int col_plane = cf / nF;
+  const int cj = cf - col_plane * nF;
+  const bool is_sc = a.G == 2 && cj < a.Cn;
+  const int ch = is_sc ? cj : cj - (a.G - 1) * a.Cn;
+  const int n = col_plane ? c : r;
+  if (a.flags[(size_t)bi * a.N + r] == 0.f || a.flags[(size_t)bi * a.N + c] == 0.f) return 0.f;
+  const size_t off = ((size_t)bi * a.N + n) * a.Cn + ch;
+  if (is_sc) return a.sc_node ? a.sc_node[off] : 0.f;
+  return cin * a.node[off];
+}
+
+// the same taps as a GEMM operand (backward recompute): bf16 [T, Kp], column k = (channel, i, j) of the conv weight
+__global__ __launch_bounds__(256) void k_na_im2col(NaEmbedArgs a, bf16* __restrict__ out, int Kp) {
+  const int hp = a.N / a.p, L = hp * hp, pp = a.p * a.p, kin = a.in_ch * pp;
+  const size_t total = (size_t)a.B * L * Kp;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int k = (int)(i % Kp);
+    const size_t row = i / Kp;
+    float v = 0.f;
+    if (k < kin) {
+      const int bi = (int)(row / L), rem = (int)(row - (size_t)bi * L);
+      const int Y = rem / hp, X = rem - Y * hp;
+      const int ci = k / pp, ij = k - ci * pp;
+      const int ii = ij / a.p, jj = ij - ii * a.p;
+      v = na_input_value(a, bi, ci, Y * a.p + ii, X * a.p + jj);
+    }
+    out[i] = (bf16)v;
+  }
+}
+
 template <int LANES, int V>
 __global__ __launch_bounds__(256) void k_na_embed(NaEmbedArgs a) {
   extern __shared__ __attribute__((aligned(16))) float smem[];
@@ -38,7 +80,6 @@ __global__ __launch_bounds__(256) void k_na_embed(NaEmbedArgs a) {
     const int c = i / kin, k = i - c * kin;  // global layout [C][kin]
     sW[k * a.C + c] = a.w[i];
   }
-  const int nA = a.G * a.Ca, nF = a.G * a.Cn;
   for (int i = threadIdx.x; i < RPB * kin; i += 256) {
     const int t = i / kin, k = i - t * kin;
     const int row = min(row0 + t, rows - 1);
@@ -47,26 +88,7 @@ __global__ __launch_bounds__(256) void k_na_embed(NaEmbedArgs a) {
     const int Y = rem / hp, X = rem - Y * hp;
     const int ci = k / pp, ij = k - ci * pp;
     const int ii = ij / a.p, jj = ij - ii * a.p;
-    const int r = Y * a.p + ii, c = X * a.p + jj;
-    const float cin = a.c_in ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f;
-    float v = 0.f;
-    if (ci < nA) {
-      const bool is_sc = a.G == 2 && ci < a.Ca;
-      const int ch = is_sc ? ci : ci - (a.G - 1) * a.Ca;
-      const size_t off = (((size_t)bi * a.Ca + ch) * a.N + r) * a.N + c;
-      if (is_sc) v = a.sc_adj ? a.sc_adj[off] : 0.f;
-      else v = cin * a.adj[off];
-    } else {
-      const int cf = ci - nA;
-      const int col_plane = cf / nF;
-      const int cj = cf - col_plane * nF;
-      const bool is_sc = a.G == 2 && cj < a.Cn;
-      const int ch = is_sc ? cj : cj - (a.G - 1) * a.Cn;
-      const int n = col_plane ? c : r;
-      const bool m = a.flags[(size_t)bi * a.N + r] != 0.f && a.flags[(size_t)bi * a.N + c] != 0.f;
-      const size_t off = ((size_t)bi * a.N + n) * a.Cn + ch;
-      if (m) v = is_sc ? (a.sc_node ? a.sc_node[off] : 0.f) : cin * a.node[off];
-    }
+    const float v = na_input_value(a, bi, ci, Y * a.p + ii, X * a.p + jj);
     sIn[i] = v;
   }
   __syncthreads();
@@ -217,6 +239,147 @@ __global__ __launch_bounds__(128) void k_na_pool(const bf16* __restrict__ rep, i
   pooled[(size_t)blockIdx.x * ldr + ch] = (bf16)(acc / (float)N);
 }
 
+
+// ---- backward of the tail ---------------------------------------------------------------------------------
+// dF of the adjacency head in token-patch row order: dy[m, ca] = mask * c_out * 0.5 (dD[b,ca,r,c] + dD[b,ca,c,r])
+// (derivative of mask -> symmetrise -> c_skip x + c_out F -> mask, :1016-1018 and precond.py:102-104)
+__global__ __launch_bounds__(256) void k_na_dadj(const float* __restrict__ dD, const float* __restrict__ flags,
+                                                 const float* __restrict__ coef, int B, int N, int p, int Ca,
+                                                 float* __restrict__ dy) {
+  const int hp = N / p, L = hp * hp, pp = p * p;
+  const size_t total = (size_t)B * N * N * Ca;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ca = (int)(i % Ca);
+    const size_t m = i / Ca;
+    const int ij = (int)(m % pp);
+    const size_t t = m / pp;
+    const int bi = (int)(t / L), rem = (int)(t - (size_t)bi * L);
+    const int Y = rem / hp, X = rem - Y * hp;
+    const int ii = ij / p, jj = ij - ii * p;
+    const int r = Y * p + ii, c = X * p + jj;
+    float v = 0.f;
+    if (flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f) {
+      const size_t base = ((size_t)bi * Ca + ca) * N * N;
+      const float c_out = coef ? coef[4 * bi + 1] : 1.f;
+      v = 0.5f * c_out * (dD[base + (size_t)r * N + c] + dD[base + (size_t)c * N + r]);
+    }
+    dy[i] = v;
+  }
+}
+
+// node head: dy[row, cn] = flag * c_out * dD[row, cn]
+__global__ __launch_bounds__(256) void k_na_dnode(const float* __restrict__ dD, const float* __restrict__ flags,
+                                                  const float* __restrict__ coef, size_t total, int N, int Cn,
+                                                  float* __restrict__ dy) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t row = i / Cn;
+  const int bi = (int)(row / N);
+  dy[i] = flags[row] != 0.f ? (coef ? coef[4 * bi + 1] : 1.f) * dD[i] : 0.f;
+}
+
+// gradient of the narrow output layer w.r.t. its input: dact[row, c] = sum_o dy[row, o] W2[o, c]  (bf16 [rows, ld],
+// padding columns zero); one thread per (row, 8 channels)
+__global__ __launch_bounds__(256) void k_na_head_bwd(const float* __restrict__ dy, const float* __restrict__ w2, int rows,
+                                                     int C, int Co, bf16* __restrict__ dact, int ld) {
+  const int chunks = ld / 8;
+  const size_t total = (size_t)rows * chunks;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % chunks);
+    const size_t row = i / chunks;
+    float acc[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) acc[e] = 0.f;
+    for (int o = 0; o < Co; ++o) {
+      const float d = dy[row * Co + o];
+#pragma unroll
+      for (int e = 0; e < 8; ++e)
+        if (8 * ch + e < C) acc[e] = fmaf(d, w2[(size_t)o * C + 8 * ch + e], acc[e]);
+    }
+    bf16x8 v;
+#pragma unroll
+    for (int e = 0; e < 8; ++e) v[e] = (bf16)acc[e];
+    *reinterpret_cast<bf16x8*>(dact + row * ld + 8 * ch) = v;
+  }
+}
+
+// backward of k_na_pool: drep[m(b, r, c), ch] = flag_r flag_c / N * dpooled[b N + r, ch]   (fp32 [P, C], full overwrite)
+__global__ __launch_bounds__(256) void k_na_pool_bwd(const float* __restrict__ dpooled, const float* __restrict__ flags,
+                                                     int B, int N, int p, int C, float* __restrict__ drep) {
+  const int hp = N / p, L = hp * hp, pp = p * p;
+  const size_t total = (size_t)B * N * N * C;
+  const float inv = 1.0f / (float)N;
+  for (size_t i = (size_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (size_t)gridDim.x * 256) {
+    const int ch = (int)(i % C);
+    const size_t m = i / C;
+    const int ij = (int)(m % pp);
+    const size_t t = m / pp;
+    const int bi = (int)(t / L), rem = (int)(t - (size_t)bi * L);
+    const int Y = rem / hp, X = rem - Y * hp;
+    const int ii = ij / p, jj = ij - ii * p;
+    const int r = Y * p + ii, c = X * p + jj;
+    float v = 0.f;
+    if (flags[(size_t)bi * N + r] != 0.f && flags[(size_t)bi * N + c] != 0.f)
+      v = inv * dpooled[((size_t)bi * N + r) * C + ch];
+    drep[i] = v;
+  }
+}
+
+// ---- node-feature halves of the training objective and loss --------------------------------------------------
+// noisy = clean + mask(sigma_b * raw)   (runner/objectives/edm.py:243-247; clean is not re-masked)
+__global__ __launch_bounds__(256) void k_nodes_noisy(size_t total, int N, int Cn, const float* __restrict__ clean,
+                                                     const float* __restrict__ raw, const float* __restrict__ flags,
+                                                     const float* __restrict__ sigmas, float* __restrict__ noisy) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t row = i / Cn;
+  noisy[i] = clean[i] + (flags[row] != 0.f ? sigmas[row / N] * raw[i] : 0.f);
+}
+
+// loss_b = w_b sum_{n,c} flag (pred - target)^2 / (sum flags_b) / Cn * node_loss_weight  (loss/rainbow_loss.py:211-248);
+// one block per graph, fixed summation order
+__global__ __launch_bounds__(256) void k_nodes_loss(int N, int Cn, const float* __restrict__ pred,
+                                                    const float* __restrict__ target, const float* __restrict__ flags,
+                                                    const float* __restrict__ weights, float lw, float* __restrict__ loss) {
+  __shared__ float red[8];
+  const int bi = blockIdx.x;
+  float acc = 0.f, cnt = 0.f;
+  for (int i = threadIdx.x; i < N * Cn; i += 256) {
+    const int n = i / Cn;
+    if (flags[(size_t)bi * N + n] != 0.f) {
+      const float d = pred[(size_t)bi * N * Cn + i] - target[(size_t)bi * N * Cn + i];
+      acc = fmaf(d, d, acc);
+    }
+  }
+  for (int n = threadIdx.x; n < N; n += 256) cnt += flags[(size_t)bi * N + n];
+  acc = group_sum<64>(acc);
+  cnt = group_sum<64>(cnt);
+  if ((threadIdx.x & 63) == 0) { red[threadIdx.x >> 6] = acc; red[4 + (threadIdx.x >> 6)] = cnt; }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const float s = (red[0] + red[1]) + (red[2] + red[3]);
+    const float c = (red[4] + red[5]) + (red[6] + red[7]);
+    loss[bi] = (weights ? weights[bi] : 1.f) * s / c / (float)Cn * lw;
+  }
+}
+
+__global__ __launch_bounds__(256) void k_nodes_loss_bwd(size_t total, int N, int Cn, const float* __restrict__ pred,
+                                                        const float* __restrict__ target, const float* __restrict__ flags,
+                                                        const float* __restrict__ weights, const float* __restrict__ gl,
+                                                        float lw, float* __restrict__ gp) {
+  const size_t i = (size_t)blockIdx.x * 256 + threadIdx.x;
+  if (i >= total) return;
+  const size_t row = i / Cn;
+  const int bi = (int)(row / N);
+  float v = 0.f;
+  if (flags[row] != 0.f) {
+    float cnt = 0.f;
+    for (int n = 0; n < N; ++n) cnt += flags[(size_t)bi * N + n];
+    v = 2.f * (pred[i] - target[i]) * (weights ? weights[bi] : 1.f) * gl[bi] * lw / cnt / (float)Cn;
+  }
+  gp[i] = v;
+}
+
 // ---- node-feature Heun updates: x [B, N, Cn], flags [B, N] ----
 __global__ __launch_bounds__(256) void k_nodes_churn(size_t total, int Cn, const float* __restrict__ x,
                                                      const float* __restrict__ raw, const float* __restrict__ flags,
@@ -255,6 +418,68 @@ __global__ __launch_bounds__(256) void k_nodes_correct(size_t total, int Cn, con
 }
 
 }  // namespace
+
+
+static NaEmbedArgs na_embed_args(const swg_net* net, const swg_nodeadj* na, int B, const float* adj, const float* node,
+                                 const float* sc_adj, const float* sc_node, const float* flags, const float* c_in,
+                                 int c_in_stride, const float* cond, int cond_stride, float* tok) {
+  const int G = net->self_cond ? 2 : 1;
+  NaEmbedArgs a = {adj, node, sc_adj, sc_node, flags, c_in, c_in_stride, cond, cond_stride, net->pe_cond_off,
+                   net->pe_w, net->pe_b, net->pe_ln.g, net->pe_ln.b, tok,
+                   B, net->N, net->p, net->in_ch, net->C0, G, na->Ca, na->Cn};
+  return a;
+}
+
+static inline unsigned na_grid(size_t items) { return (unsigned)max((size_t)1, min((size_t)4096, (items + 255) / 256)); }
+
+int launch_na_im2col(const swg_net* net, const swg_nodeadj* na, int B, const float* adj, const float* node,
+                     const float* sc_adj, const float* sc_node, const float* flags, const float* c_in, int c_in_stride,
+                     bf16* out, int Kp, hipStream_t s) {
+  const int G = net->self_cond ? 2 : 1;
+  if (net->in_ch != G * (na->Ca + 2 * na->Cn) || net->N % net->p) return SWG_E_SHAPE;
+  NaEmbedArgs a = na_embed_args(net, na, B, adj, node, sc_adj, sc_node, flags, c_in, c_in_stride, nullptr, 0, nullptr);
+  const int hp = net->N / net->p;
+  const size_t total = (size_t)B * hp * hp * Kp;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, 2.0 * total, s);
+  hipLaunchKernelGGL(k_na_im2col, dim3(na_grid(total)), dim3(256), 0, s, a, out, Kp);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_na_dadj(const float* dD, const float* flags, const float* coef, int B, int N, int p, int Ca, float* dy,
+                   hipStream_t s) {
+  const size_t total = (size_t)B * N * N * Ca;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, 12.0 * total, s);
+  hipLaunchKernelGGL(k_na_dadj, dim3(na_grid(total)), dim3(256), 0, s, dD, flags, coef, B, N, p, Ca, dy);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_na_dnode(const float* dD, const float* flags, const float* coef, int B, int N, int Cn, float* dy,
+                    hipStream_t s) {
+  const size_t total = (size_t)B * N * Cn;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, 8.0 * total, s);
+  hipLaunchKernelGGL(k_na_dnode, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, dD, flags, coef, total, N, Cn, dy);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_na_head_bwd(const float* dy, const float* w2, int rows, int C, int Co, bf16* dact, int ld, hipStream_t s) {
+  if (ld % 8 || ld < C) return SWG_E_SHAPE;
+  const size_t total = (size_t)rows * (ld / 8);
+  SwgProfScope ps(KID_BWD_ROWS, 2.0 * rows * (double)C * Co, rows * (4.0 * Co + 2.0 * ld), s);
+  hipLaunchKernelGGL(k_na_head_bwd, dim3(na_grid(total)), dim3(256), 0, s, dy, w2, rows, C, Co, dact, ld);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_na_pool_bwd(const float* dpooled, const float* flags, int B, int N, int p, int C, float* drep, hipStream_t s) {
+  const size_t total = (size_t)B * N * N * C;
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, 4.0 * total, s);
+  hipLaunchKernelGGL(k_na_pool_bwd, dim3(na_grid(total)), dim3(256), 0, s, dpooled, flags, B, N, p, C, drep);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_na_embed(const swg_net* net, const swg_nodeadj* na, int B, const float* adj, const float* node,
                     const float* sc_adj, const float* sc_node, const float* flags, const float* c_in, int c_in_stride,
@@ -346,6 +571,39 @@ int swg_heun_nodes_correct(int32_t B, int32_t N, int32_t Cn, const float* x_hat,
   SwgProfScope ps(KID_HEUN, 0.0, 20.0 * total, (hipStream_t)stream);
   hipLaunchKernelGGL(k_nodes_correct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total,
                      Cn, x_hat, x_prime, d_cur, denoised2, node_flags, 1.0f / t_prime, h, x_next);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_nodes_objective(int32_t B, int32_t N, int32_t Cn, const float* clean, const float* raw_noise,
+                        const float* node_flags, const float* sigmas, float* noisy, void* stream) {
+  if (!clean || !raw_noise || !node_flags || !sigmas || !noisy) return SWG_E_NULL;
+  if (B <= 0 || N <= 0 || Cn <= 0) return SWG_E_SHAPE;
+  const size_t total = (size_t)B * N * Cn;
+  hipLaunchKernelGGL(k_nodes_noisy, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total, N, Cn,
+                     clean, raw_noise, node_flags, sigmas, noisy);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_nodes_loss(int32_t B, int32_t N, int32_t Cn, const float* pred, const float* target, const float* node_flags,
+                   const float* weights, float node_loss_weight, float* loss, void* stream) {
+  if (!pred || !target || !node_flags || !loss) return SWG_E_NULL;
+  if (B <= 0 || N <= 0 || Cn <= 0) return SWG_E_SHAPE;
+  hipLaunchKernelGGL(k_nodes_loss, dim3(B), dim3(256), 0, (hipStream_t)stream, N, Cn, pred, target, node_flags, weights,
+                     node_loss_weight, loss);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int swg_nodes_loss_bwd(int32_t B, int32_t N, int32_t Cn, const float* pred, const float* target, const float* node_flags,
+                       const float* weights, const float* grad_loss, float node_loss_weight, float* grad_pred,
+                       void* stream) {
+  if (!pred || !target || !node_flags || !grad_loss || !grad_pred) return SWG_E_NULL;
+  if (B <= 0 || N <= 0 || Cn <= 0) return SWG_E_SHAPE;
+  const size_t total = (size_t)B * N * Cn;
+  hipLaunchKernelGGL(k_nodes_loss_bwd, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, total, N,
+                     Cn, pred, target, node_flags, weights, grad_loss, node_loss_weight, grad_pred);
   SWG_LAUNCH_CHECK();
   return 0;
 }

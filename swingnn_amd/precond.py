@@ -94,9 +94,7 @@ class NodeAdjPrecond(Precond):
     def forward(self, adjs, nodes=None, node_flags=None, sigmas=None, self_cond_adjs=None, self_cond_nodes=None,
                 *args, **model_kwargs):
         m = self.model
-        if torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters()):
-            raise NotImplementedError("swingnn_amd.NodeAdjPrecond: training backward of the molecule path is not built "
-                                      "yet; call under torch.no_grad()")
+        with_grad = torch.is_grad_enabled() and any(p.requires_grad for p in m.parameters())
         sigmas = torch.as_tensor(sigmas, device=adjs.device).reshape(-1)
         uniform = sigmas.numel() == 1 or (sigmas.dim() == 1 and sigmas.stride(0) == 0)
         if not uniform and sigmas.numel() != adjs.shape[0]:
@@ -109,8 +107,13 @@ class NodeAdjPrecond(Precond):
             sa, sn = E.nodeadj_pass(cache, 1, a, n, node_flags, labels, uniform,
                                     sa if m.self_condition else None, sn if m.self_condition else None)
         acc = None if self.symmetry_check == 'off' else self._acc(adjs.device)
-        Da, Dn = E.nodeadj_pass(cache, 1, a, n, node_flags, labels, uniform, sa if m.self_condition else None,
-                                sn if m.self_condition else None, sym_err=acc)
+        if with_grad:  # training step (runner/trainer/trainer_node_adj.py:97-99)
+            from .train import denoise_nodeadj_with_grad
+            Da, Dn = denoise_nodeadj_with_grad(m, 1, a, n, node_flags, sigmas.expand(a.shape[0]) if uniform else sigmas,
+                                               sa if m.self_condition else None, sn if m.self_condition else None, acc)
+        else:
+            Da, Dn = E.nodeadj_pass(cache, 1, a, n, node_flags, labels, uniform, sa if m.self_condition else None,
+                                    sn if m.self_condition else None, sym_err=acc)
         if self.symmetry_check == 'eager':
             self.assert_symmetric()
         return m._adj_out(Da), m._node_out(Dn)

@@ -436,9 +436,6 @@ class NodeAdjSwinGNN(nn.Module):
     def forward(self, adj, node, node_flags, noise_labels, self_cond_x=None, self_cond_feat=None):
         """adj [B,N,N] | [B,Ca,N,N], node [B,N] | [B,N,Cn], node_flags [B,N], noise_labels [B] -> (adj_out, node_out)
         in the layouts of the inputs (reference :960-1021)."""
-        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
-            raise NotImplementedError("swingnn_amd.NodeAdjSwinGNN: the training backward of the molecule head / tail is "
-                                      "not built yet; call under torch.no_grad()")
         if not self.self_condition:
             self_cond_x = self_cond_feat = None
         cache = E.get_cache(self)
@@ -446,6 +443,11 @@ class NodeAdjSwinGNN(nn.Module):
         labels = noise_labels.reshape(-1)
         if labels.numel() == 1 and a.shape[0] != 1:
             labels = labels.expand(a.shape[0])
+        if torch.is_grad_enabled() and any(p.requires_grad for p in self.parameters()):
+            from .train import denoise_nodeadj_with_grad
+            oa, on = denoise_nodeadj_with_grad(self, 0, a, self._node_in(node.to(torch.float32)), node_flags, labels,
+                                               self._adj_in(self_cond_x), self._node_in(self_cond_feat))
+            return self._adj_out(oa), self._node_out(on)
         oa, on = E.nodeadj_pass(cache, 0, a, self._node_in(node.to(torch.float32)), node_flags, labels, False,
                                 self._adj_in(self_cond_x), self._node_in(self_cond_feat))
         return self._adj_out(oa), self._node_out(on)

@@ -51,14 +51,26 @@ class TrainCache:
                 self.wt[name] = _wt(p)
         pe = model.patch_embed
         self.pe_wb = _padded_bf16(pe.proj.weight.detach().reshape(model.embed_dim, -1))
-        ro_w, _ = E.collapse_read_out(model.read_out, pe.patch_size[0])
-        self.ro_wb = _padded_bf16(ro_w)
+        self.nodeadj = cache.nodeadj is not None
+        if self.nodeadj:  # collapsed read-out map [p*p*Cp, Cp] transposed: operand of dxn = drep Wro
+            p_, C0 = pe.patch_size[0], model.embed_dim
+            weff, _ = E.collapse_read_out_nodeadj(model.read_out, p_)
+            Cp = _kp(C0)
+            wt = torch.zeros((C0, p_ * p_, Cp), dtype=torch.bfloat16, device=weff.device)
+            wt[:, :, :C0] = weff.permute(2, 0, 1)          # [Cin, ij, Cout]
+            self.ro_wt = wt.reshape(C0, p_ * p_ * Cp).contiguous()
+        else:
+            ro_w, _ = E.collapse_read_out(model.read_out, pe.patch_size[0])
+            self.ro_wb = _padded_bf16(ro_w)
         self._ws = {}
 
     def ws_bytes(self, cache, B):
         n = self._ws.get(B)
         if n is None:
-            n = int(L.lib.swg_train_workspace_bytes(C.byref(cache.net), B))
+            if self.nodeadj:
+                n = int(L.lib.swg_nodeadj_train_workspace_bytes(C.byref(cache.net), C.byref(cache.nodeadj), B))
+            else:
+                n = int(L.lib.swg_train_workspace_bytes(C.byref(cache.net), B))
             if n == 0:
                 raise L.SwgError("swg_train_workspace_bytes: unsupported network geometry")
             self._ws[B] = n
@@ -116,6 +128,42 @@ def _c(ptr_struct):
     return C.byref(ptr_struct)
 
 
+def _trunk_forward(cache, B, tok, cond, ct, wp, wn, st):
+    """Encoder / decoder layers (model/swin_gnn/swin_gnn.py:735-746) through the op-level entry points, keeping every
+    op's input.  -> (final tokens, saved)"""
+    net = cache.net
+    f32 = dict(dtype=torch.float32, device=tok.device)
+    saved, skips = [], {}
+    cur = tok
+    for li in range(net.n_layers):
+        ly = cache.layers[li]
+        if ly.up:
+            up = ly.up.contents
+            si = net.n_layers - 1 - li
+            skip = skips[si]
+            out = torch.empty((B, 4 * up.res * up.res, up.Cin // 4), **f32)
+            _run(L.lib.swg_patch_expand_fwd, "swg_patch_expand_fwd", ly.up, B, cur.data_ptr(), skip.data_ptr(),
+                 out.data_ptr(), wp, wn, st)
+            saved.append(("up", li, si, cur, skip))
+            cur = out
+        for j in range(ly.n_blocks):
+            blk = C.byref(ly.blocks[j])
+            mid = torch.empty_like(cur)
+            _run(L.lib.swg_wattn_fwd, "swg_wattn_fwd", blk, B, cur.data_ptr(), cond.data_ptr(), ct, mid.data_ptr(), wp, wn, st)
+            out = torch.empty_like(cur)
+            _run(L.lib.swg_ln_mlp_fwd, "swg_ln_mlp_fwd", blk, B, mid.data_ptr(), out.data_ptr(), wp, wn, st)
+            saved.append(("blk", li, j, cur, mid))
+            cur = out
+        if ly.down:
+            dn = ly.down.contents
+            out = torch.empty((B, (dn.res // 2) ** 2, 2 * dn.C), **f32)
+            _run(L.lib.swg_patch_merge_fwd, "swg_patch_merge_fwd", ly.down, B, cur.data_ptr(), out.data_ptr(), wp, wn, st)
+            saved.append(("down", li, cur))
+            skips[li] = out
+            cur = out
+    return cur, saved
+
+
 def forward_keep(model, mode, x, node_flags, labels, self_cond, sym_err=None):
     """SwinGNN / Precond-core forward through the op-level entry points; returns (D, saved state for backward)."""
     cache = E.get_cache(model)
@@ -145,34 +193,7 @@ def forward_keep(model, mode, x, node_flags, labels, self_cond, sym_err=None):
     tok = torch.empty((B, hp * hp, net.C0), **f32)
     _run(L.lib.swg_patch_embed_fwd, "swg_patch_embed_fwd", _c(net), B, x.data_ptr(), E._ptr(sc), coef.data_ptr() + 8, 4,
          cond.data_ptr(), ct, tok.data_ptr(), st)
-    saved, skips = [], {}
-    cur = tok
-    for li in range(net.n_layers):
-        ly = cache.layers[li]
-        if ly.up:
-            up = ly.up.contents
-            si = net.n_layers - 1 - li
-            skip = skips[si]
-            out = torch.empty((B, 4 * up.res * up.res, up.Cin // 4), **f32)
-            _run(L.lib.swg_patch_expand_fwd, "swg_patch_expand_fwd", ly.up, B, cur.data_ptr(), skip.data_ptr(),
-                 out.data_ptr(), wp, wn, st)
-            saved.append(("up", li, si, cur, skip))
-            cur = out
-        for j in range(ly.n_blocks):
-            blk = C.byref(ly.blocks[j])
-            mid = torch.empty_like(cur)
-            _run(L.lib.swg_wattn_fwd, "swg_wattn_fwd", blk, B, cur.data_ptr(), cond.data_ptr(), ct, mid.data_ptr(), wp, wn, st)
-            out = torch.empty_like(cur)
-            _run(L.lib.swg_ln_mlp_fwd, "swg_ln_mlp_fwd", blk, B, mid.data_ptr(), out.data_ptr(), wp, wn, st)
-            saved.append(("blk", li, j, cur, mid))
-            cur = out
-        if ly.down:
-            dn = ly.down.contents
-            out = torch.empty((B, (dn.res // 2) ** 2, 2 * dn.C), **f32)
-            _run(L.lib.swg_patch_merge_fwd, "swg_patch_merge_fwd", ly.down, B, cur.data_ptr(), out.data_ptr(), wp, wn, st)
-            saved.append(("down", li, cur))
-            skips[li] = out
-            cur = out
+    cur, saved = _trunk_forward(cache, B, tok, cond, ct, wp, wn, st)
     D = torch.empty_like(x)
     _run(L.lib.swg_readout_sym_precond_fwd, "swg_readout_sym_precond_fwd", _c(net), B, cur.data_ptr(), x.data_ptr(),
          flags.data_ptr(), coef.data_ptr(), D.data_ptr(), E._ptr(sym_err), wp, wn, st)
@@ -220,43 +241,11 @@ def _readout_chain_grads(model, p, dweff, dbeff):
     return dict(zip([id(t) for t in leaves], [g.float() for g in grads]))
 
 
-def backward_all(model, state, dD):
-    """-> {id(param): grad} for every parameter of `model`."""
-    cache, tc = state["cache"], state["tc"]
-    net = cache.net
-    B = state["B"]
-    dev = dD.device
-    dD = E._as_f32(dD)
-    sync = getattr(model, "_swg_grad_sync", None)
-    if sync is not None:  # data parallel: sum over ranks of (dD / W)-gradients = the DDP average
-        dD = dD / sync.world_size
-    st = E.stream_ptr()
-    ws = E.workspace(dev, max(cache.ws_bytes(B), tc.ws_bytes(cache, B)))
-    wp, wn = ws.data_ptr(), ws.numel()
-    f32 = dict(dtype=torch.float32, device=dev)
-    book = GradBook(model, dev)
-    names = _layer_names(model)
-    if sync is not None:
-        sync.begin(book.flat)
-    first_of = {}  # flat offset of the first parameter of every module prefix (modules own contiguous slices)
-    for pname, o in book.offset.items():
-        for depth in (2, 3, 4):
-            first_of.setdefault(".".join(pname.split(".")[:depth]), o)
-    ct = net.cond_total
-    cond = state["cond"]
-    p = net.p
-    dro_w = torch.zeros((net.C0, p * p), **f32)
-    dro_b = torch.zeros((32,), **f32)
-    ends = L.SwgEndsTrain(tc.pe_wb.data_ptr(), book.ptr("patch_embed.proj.weight"), book.ptr("patch_embed.proj.bias"),
-                          _ln_train(book, "patch_embed.norm"), _ln_train(book, "norm"), tc.ro_wb.data_ptr(),
-                          dro_w.data_ptr(), dro_b.data_ptr())
-    tok_final = state["tok_final"]
-    dcur = torch.empty_like(tok_final)
-    _run(L.lib.swg_readout_sym_precond_bwd, "swg_readout_sym_precond_bwd", _c(net), _c(ends), B, tok_final.data_ptr(),
-         state["flags"].data_ptr(), state["coef"].data_ptr(), dD.data_ptr(), dcur.data_ptr(), wp, wn, st)
-    dcond = torch.zeros((B, ct), **f32)
+def _trunk_backward(cache, tc, book, names, saved, dcur, cond, ct, dcond, B, wp, wn, st, sync, first_of):
+    """Backward through the encoder / decoder layers: gradient of the final tokens -> gradient of the embedded tokens;
+    parameter gradients accumulate into `book`, conditioning gradients into `dcond`."""
     dskips = {}
-    for entry in reversed(state["saved"]):
+    for entry in reversed(saved):
         kind, li = entry[0], entry[1]
         ly = cache.layers[li]
         if kind == "down":
@@ -297,6 +286,45 @@ def backward_all(model, state, dD):
             dcur = dx
         if sync is not None:  # this module and everything after it in parameter order is complete
             sync.ready_from(first_of[pre])
+    return dcur
+
+
+def backward_all(model, state, dD):
+    """-> {id(param): grad} for every parameter of `model`."""
+    cache, tc = state["cache"], state["tc"]
+    net = cache.net
+    B = state["B"]
+    dev = dD.device
+    dD = E._as_f32(dD)
+    sync = getattr(model, "_swg_grad_sync", None)
+    if sync is not None:  # data parallel: sum over ranks of (dD / W)-gradients = the DDP average
+        dD = dD / sync.world_size
+    st = E.stream_ptr()
+    ws = E.workspace(dev, max(cache.ws_bytes(B), tc.ws_bytes(cache, B)))
+    wp, wn = ws.data_ptr(), ws.numel()
+    f32 = dict(dtype=torch.float32, device=dev)
+    book = GradBook(model, dev)
+    names = _layer_names(model)
+    if sync is not None:
+        sync.begin(book.flat)
+    first_of = {}  # flat offset of the first parameter of every module prefix (modules own contiguous slices)
+    for pname, o in book.offset.items():
+        for depth in (2, 3, 4):
+            first_of.setdefault(".".join(pname.split(".")[:depth]), o)
+    ct = net.cond_total
+    cond = state["cond"]
+    p = net.p
+    dro_w = torch.zeros((net.C0, p * p), **f32)
+    dro_b = torch.zeros((32,), **f32)
+    ends = L.SwgEndsTrain(tc.pe_wb.data_ptr(), book.ptr("patch_embed.proj.weight"), book.ptr("patch_embed.proj.bias"),
+                          _ln_train(book, "patch_embed.norm"), _ln_train(book, "norm"), tc.ro_wb.data_ptr(),
+                          dro_w.data_ptr(), dro_b.data_ptr())
+    tok_final = state["tok_final"]
+    dcur = torch.empty_like(tok_final)
+    _run(L.lib.swg_readout_sym_precond_bwd, "swg_readout_sym_precond_bwd", _c(net), _c(ends), B, tok_final.data_ptr(),
+         state["flags"].data_ptr(), state["coef"].data_ptr(), dD.data_ptr(), dcur.data_ptr(), wp, wn, st)
+    dcond = torch.zeros((B, ct), **f32)
+    dcur = _trunk_backward(cache, tc, book, names, state["saved"], dcur, cond, ct, dcond, B, wp, wn, st, sync, first_of)
     _run(L.lib.swg_patch_embed_bwd, "swg_patch_embed_bwd", _c(net), _c(ends), B, state["x"].data_ptr(),
          E._ptr(state["sc"]), state["coef"].data_ptr() + 8, 4, cond.data_ptr(), ct, dcur.data_ptr(), dcond.data_ptr(), ct,
          wp, wn, st)
@@ -330,3 +358,138 @@ class DenoiserFn(torch.autograd.Function):
 def denoise_with_grad(model, mode, x, node_flags, labels, self_cond, sym_err=None):
     params = tuple(model.parameters())
     return DenoiserFn.apply(model, mode, x, node_flags, labels, self_cond, sym_err, *params)
+
+
+# ---- molecule path: NodeAdjPrecond(NodeAdjSwinGNN) (runner/trainer/trainer_node_adj.py:95-131) --------------------
+def forward_keep_nodeadj(model, mode, adj, node, node_flags, labels, sc_adj, sc_node, sym_err=None):
+    """adj [B,Ca,N,N], node [B,N,Cn] (library layout) -> ((D_adj, D_node), saved state)."""
+    cache = E.get_cache(model)
+    tc = get_train_cache(model, cache)
+    net, na = cache.net, cache.nodeadj
+    adj, node = E._as_f32(adj), E._as_f32(node)
+    flags = E._as_f32(node_flags)
+    labels = E._as_f32(labels.reshape(-1))
+    sc_adj = None if sc_adj is None else E._as_f32(sc_adj)
+    sc_node = None if sc_node is None else E._as_f32(sc_node)
+    B, N = adj.shape[0], adj.shape[-1]
+    if adj.dim() != 4 or adj.shape[1] != na.Ca or adj.shape[2] != N or N != net.N:
+        raise AssertionError(f"Input image size ({adj.shape[-2]}*{N}) doesn't match model ({net.N}*{net.N}).")
+    if tuple(node.shape) != (B, N, na.Cn):
+        raise AssertionError(f"node features {tuple(node.shape)} do not match [B, N, {na.Cn}]")
+    if labels.numel() != B:
+        raise AssertionError("one noise label per sample is required in training")
+    dev = adj.device
+    st = E.stream_ptr()
+    ws = E.workspace(dev, max(cache.ws_bytes(B), tc.ws_bytes(cache, B)))
+    wp, wn = ws.data_ptr(), ws.numel()
+    f32 = dict(dtype=torch.float32, device=dev)
+    coef = torch.empty((B, 4), **f32)
+    cnoise = torch.empty((B,), **f32)
+    _run(L.lib.swg_edm_coef, "swg_edm_coef", B, labels.data_ptr(), 0, mode, coef.data_ptr(), cnoise.data_ptr(), st)
+    ct = net.cond_total
+    cond = torch.empty((B, ct), **f32)
+    _run(L.lib.swg_noise_embed, "swg_noise_embed", _c(net), B, cnoise.data_ptr(), cond.data_ptr(), wp, wn, st)
+    hp = N // net.p
+    tok = torch.empty((B, hp * hp, net.C0), **f32)
+    _run(L.lib.swg_nodeadj_embed_fwd, "swg_nodeadj_embed_fwd", _c(net), _c(na), B, adj.data_ptr(), node.data_ptr(),
+         E._ptr(sc_adj), E._ptr(sc_node), flags.data_ptr(), coef.data_ptr() + 8, 4, cond.data_ptr(), ct, tok.data_ptr(), st)
+    cur, saved = _trunk_forward(cache, B, tok, cond, ct, wp, wn, st)
+    Da, Dn = torch.empty_like(adj), torch.empty_like(node)
+    _run(L.lib.swg_nodeadj_readout_fwd, "swg_nodeadj_readout_fwd", _c(net), _c(na), B, cur.data_ptr(), adj.data_ptr(),
+         node.data_ptr(), flags.data_ptr(), coef.data_ptr() if mode else None, Da.data_ptr(), Dn.data_ptr(),
+         E._ptr(sym_err), wp, wn, st)
+    state = dict(cache=cache, tc=tc, adj=adj, node=node, flags=flags, sc_adj=sc_adj, sc_node=sc_node, coef=coef,
+                 cnoise=cnoise, cond=cond, saved=saved, tok_final=cur, B=B, mode=mode)
+    return (Da, Dn), state
+
+
+def _readout_chain_grads_nodeadj(model, p, dweff, dbeff):
+    """torch chain rule through engine.collapse_read_out_nodeadj (float64): dweff [p*p, Cout, Cin], dbeff [Cout]."""
+    ro = model.read_out
+    leaves = [ro[0].weight, ro[0].bias, ro[1].weight, ro[1].bias, ro[2].weight, ro[2].bias]
+    det = [t.detach().double().requires_grad_(True) for t in leaves]
+    with torch.enable_grad():
+        W0, b0, W1, b1, W2, b2 = det
+        M = W2[:, :, 0, 0] @ W1[:, :, 0, 0]
+        weff = torch.einsum("oc,icyx->yxoi", M, W0).reshape(p * p, M.shape[0], W0.shape[0])
+        beff = M @ b0 + W2[:, :, 0, 0] @ b1 + b2
+    grads = torch.autograd.grad([weff, beff], det, grad_outputs=[dweff.double(), dbeff.double()])
+    return dict(zip([id(t) for t in leaves], [g.float() for g in grads]))
+
+
+def backward_all_nodeadj(model, state, dDa, dDn):
+    cache, tc = state["cache"], state["tc"]
+    net, na = cache.net, cache.nodeadj
+    B = state["B"]
+    dev = dDa.device
+    dDa, dDn = E._as_f32(dDa), E._as_f32(dDn)
+    sync = getattr(model, "_swg_grad_sync", None)
+    if sync is not None:
+        dDa, dDn = dDa / sync.world_size, dDn / sync.world_size
+    st = E.stream_ptr()
+    ws = E.workspace(dev, max(cache.ws_bytes(B), tc.ws_bytes(cache, B)))
+    wp, wn = ws.data_ptr(), ws.numel()
+    f32 = dict(dtype=torch.float32, device=dev)
+    book = GradBook(model, dev)
+    names = _layer_names(model)
+    if sync is not None:
+        sync.begin(book.flat)
+    first_of = {}
+    for pname, o in book.offset.items():
+        for depth in (2, 3, 4):
+            first_of.setdefault(".".join(pname.split(".")[:depth]), o)
+    ct = net.cond_total
+    cond = state["cond"]
+    p, C0 = net.p, net.C0
+    Cp = _kp(C0)
+    dro_w = torch.zeros((p * p * Cp, C0), **f32)
+    dro_b = torch.zeros((p * p * Cp,), **f32)
+    tr = L.SwgNodeAdjTrain(tc.ro_wt.data_ptr(), dro_w.data_ptr(), dro_b.data_ptr(),
+                           _lin_train(tc, book, "readout_adj_mlp.fc1"), _lin_train(tc, book, "readout_node_mlp.fc1"),
+                           book.ptr("readout_adj_mlp.fc2.weight"), book.ptr("readout_adj_mlp.fc2.bias"),
+                           book.ptr("readout_node_mlp.fc2.weight"), book.ptr("readout_node_mlp.fc2.bias"),
+                           _ln_train(book, "norm"))
+    tok_final = state["tok_final"]
+    dcur = torch.empty_like(tok_final)
+    _run(L.lib.swg_nodeadj_readout_bwd, "swg_nodeadj_readout_bwd", _c(net), _c(na), _c(tr), B, tok_final.data_ptr(),
+         state["flags"].data_ptr(), state["coef"].data_ptr() if state["mode"] else None, dDa.data_ptr(), dDn.data_ptr(),
+         dcur.data_ptr(), wp, wn, st)
+    dcond = torch.zeros((B, ct), **f32)
+    dcur = _trunk_backward(cache, tc, book, names, state["saved"], dcur, cond, ct, dcond, B, wp, wn, st, sync, first_of)
+    ends = L.SwgEndsTrain(tc.pe_wb.data_ptr(), book.ptr("patch_embed.proj.weight"), book.ptr("patch_embed.proj.bias"),
+                          _ln_train(book, "patch_embed.norm"), _ln_train(book, "norm"), None, None, None)
+    _run(L.lib.swg_nodeadj_embed_bwd, "swg_nodeadj_embed_bwd", _c(net), _c(na), _c(ends), B, state["adj"].data_ptr(),
+         state["node"].data_ptr(), E._ptr(state["sc_adj"]), E._ptr(state["sc_node"]), state["flags"].data_ptr(),
+         state["coef"].data_ptr() + 8, 4, cond.data_ptr(), ct, dcur.data_ptr(), dcond.data_ptr(), ct, wp, wn, st)
+    out = {id(prm): book.views[name] for name, prm in model.named_parameters()}
+    small = _cond_chain_grads(model, state["cnoise"], dcond)
+    dweff = dro_w.view(p * p, Cp, C0)[:, :C0, :]
+    dbeff = dro_b.view(p * p, Cp)[:, :C0].sum(0)
+    small.update(_readout_chain_grads_nodeadj(model, p, dweff, dbeff))
+    if sync is not None:
+        keys = list(small)
+        vals = sync.finish([small[k].contiguous() for k in keys])
+        small = dict(zip(keys, vals))
+    out.update(small)
+    return out
+
+
+class NodeAdjDenoiserFn(torch.autograd.Function):
+    """(D_adj, D_node) = NodeAdjPrecond core (mode 1) or NodeAdjSwinGNN.forward (mode 0) with parameter gradients."""
+
+    @staticmethod
+    def forward(ctx, model, mode, adj, node, node_flags, labels, sc_adj, sc_node, sym_err, *params):
+        (Da, Dn), state = forward_keep_nodeadj(model, mode, adj, node, node_flags, labels, sc_adj, sc_node, sym_err)
+        ctx.model, ctx.state, ctx.params = model, state, params
+        return Da, Dn
+
+    @staticmethod
+    def backward(ctx, dDa, dDn):
+        grads = backward_all_nodeadj(ctx.model, ctx.state, dDa.contiguous(), dDn.contiguous())
+        ctx.state = None
+        return (None,) * 9 + tuple(grads[id(p)] if p.requires_grad else None for p in ctx.params)
+
+
+def denoise_nodeadj_with_grad(model, mode, adj, node, node_flags, labels, sc_adj, sc_node, sym_err=None):
+    params = tuple(model.parameters())
+    return NodeAdjDenoiserFn.apply(model, mode, adj, node, node_flags, labels, sc_adj, sc_node, sym_err, *params)

@@ -49,3 +49,11 @@ def golden_nodeadj():
         arrays = {k: z[k] for k in z.files}
     with open(os.path.join(ROOT, "tests", "golden", "golden_nodeadj_meta.json")) as f:
         return arrays, json.load(f)
+
+
+@pytest.fixture(scope="session")
+def golden_nodeadj_train():
+    """Molecule-path train-step goldens from the reference modules (tests/golden/make_golden_nodeadj_train.py)."""
+    path = os.path.join(ROOT, "tests", "golden", "golden_nodeadj_train.npz")
+    with np.load(path, allow_pickle=False) as z:
+        return {k: z[k] for k in z.files}

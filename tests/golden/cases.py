@@ -101,3 +101,7 @@ NODEADJ_SAMPLER_CASES = {
     "qm9_onehot96_4": dict(net="qm9_onehot96", regime="init", steps=4, B=2, n_lo=3, n_hi=9, sanity=False, seed=82),
     "qm9_ddpm60_sanity": dict(net="qm9_ddpm60", regime="init", steps=12, B=3, n_lo=3, n_hi=9, sanity=True, seed=83),
 }
+
+# train step of the molecule path (runner/trainer/trainer_node_adj.py:95-126): (case, regime, sigma index, coin)
+NODEADJ_TRAIN_CASES = [("qm9_ddpm60", "init", 0, True), ("qm9_onehot96", "stress", 0, False),
+                       ("zinc_ddpm96", "stress", 0, True), ("qm9_ddpm60_nosc", "stress", 0, False)]

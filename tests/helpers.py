@@ -116,3 +116,38 @@ def nodeadj_inputs(cfg, B, flags, seed, sigma):
 
     sig = torch.full((B,), float(max(sigma, 1e-3))) * (1.0 + 0.1 * filler.uniform("sig", (B,), seed)).abs()
     return adj("adj", scale), node("node", scale), adj("sca", 0.5), node("scn", 0.5), sig
+
+
+def nodeadj_train_inputs(case, si):
+    """Inputs of a NODEADJ_TRAIN_CASES entry: flags, noisy adjacency / nodes, sigmas, loss weights, clean targets."""
+    cfg = case["cfg"]
+    B, N, seed = case["B"], cfg["img_size"], case["seed"]
+    flags = filler.node_flags("flags", B, N, case["n_lo"], case["n_hi"], seed)
+    adj, node, _, _, sig = nodeadj_inputs(cfg, B, flags, seed + si, case["sigmas"][si])
+    clean_a = O.mask_adjs(torch.sign(adj), flags)
+    clean_x = O.mask_nodes(torch.sign(node), flags)
+    w = (sig ** 2 + 0.25) / (sig * 0.5) ** 2
+    return flags, adj, node, sig, w, clean_a, clean_x
+
+
+def nodeadj_loss(Da, Dn, ta, tn, flags, w):
+    """NodeAdjRainbowLoss, reduction 'none', unit loss weights (loss/rainbow_loss.py:209-249) -> ([B], [B])."""
+    wa = w.reshape([-1] + [1] * (Da.dim() - 1))
+    wn = w.reshape([-1] + [1] * (Dn.dim() - 1))
+    n = flags.sum(-1)
+    sa = O.mask_adjs((Da - ta) ** 2 * wa, flags)
+    sn = O.mask_nodes((Dn - tn) ** 2 * wn, flags)
+    la = sa.flatten(1).sum(1) / n ** 2 / (Da.shape[1] if Da.dim() == 4 else 1)
+    ln = sn.flatten(1).sum(1) / n / (Dn.shape[2] if Dn.dim() == 3 else 1)
+    return la, ln
+
+
+def oracle_grads_nodeadj(sd, cfg, adj, node, flags, sig, w, clean_a, clean_x, coin):
+    leaves = {k: v.clone().requires_grad_(True) for k, v in sd.items() if torch.is_floating_point(v)}
+    full = dict(sd)
+    full.update(leaves)
+    with torch.enable_grad():
+        Da, Dn = O.nodeadj_precond_forward(full, cfg, adj, node, flags, sig, coin)
+        la, ln = nodeadj_loss(Da, Dn, clean_a, clean_x, flags, w)
+        (la.mean() + ln.mean()).backward()
+    return la.detach(), ln.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}

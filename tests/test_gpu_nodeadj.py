@@ -113,14 +113,3 @@ def test_nodeadj_sampler(S, golden_nodeadj, name):
     if c["sanity"]:
         assert H.max_abs(fa, O.mask_adjs(gta.cpu(), flags)) < 1e-5 and H.max_abs(fn, O.mask_nodes(gtn.cpu(), flags)) < 1e-5
     print(f"{name}: final max err adj {ea:.3g} nodes {en:.3g}")
-
-
-def test_nodeadj_rejects_grad(S, golden_nodeadj):
-    """No silent PyTorch path: a training-mode call raises until the molecule backward exists."""
-    g, meta = golden_nodeadj
-    pre = build(S, "qm9_ddpm60", meta, "init", 1).train()
-    cfg = NODEADJ_CASES["qm9_ddpm60"]["cfg"]
-    flags = filler.node_flags("flags", 2, 16, 3, 9, 1)
-    adj, node, _, _, sig = H.nodeadj_inputs(cfg, 2, flags, 1, 1.0)
-    with torch.enable_grad(), pytest.raises(NotImplementedError):
-        pre(adj.to(DEV), node.to(DEV), flags.to(DEV), sig.to(DEV))

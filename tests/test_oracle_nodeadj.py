@@ -71,3 +71,43 @@ def test_nodeadj_sampler(golden_nodeadj, name):
     close(fa, g[f"nasampler/{name}/final_adjs"], 1e-4); close(fn, g[f"nasampler/{name}/final_nodes"], 1e-4)
     if c["sanity"]:  # known-answer mode: a perfect denoiser reproduces the ground truth at t = 0
         close(fa, O.mask_adjs(gt[0], flags), 1e-5); close(fn, O.mask_nodes(gt[1], flags), 1e-5)
+
+
+def test_nodeadj_objective(golden_nodeadj_train):
+    """NodeAdjEDMObjectiveGenerator restated with the oracle's pieces, same CPU-generator draws in the same order."""
+    g = golden_nodeadj_train
+    for name in ("qm9_ddpm60", "qm9_onehot96"):
+        cfg = NODEADJ_CASES[name]["cfg"]
+        B, N = 5, cfg["img_size"]
+        flags = filler.node_flags("flags", B, N, 3, 9, 7)
+        ca, cx, _, _, _ = H.nodeadj_inputs(cfg, B, flags, 7, 0.0)
+        ca, cx = ca.sign(), cx.sign()
+        torch.manual_seed(7)
+        sig, w = O.edm_training_sigmas_weights(torch.randn(B))
+        raw, raw_x = torch.randn_like(ca), torch.randn_like(cx)
+        noisy = O.mask_adjs(ca + O.sym_noise_from_raw(raw) * sig.reshape([-1] + [1] * (ca.dim() - 1)), flags)
+        noisy_x = cx + O.mask_nodes(raw_x * sig.reshape([-1] + [1] * (cx.dim() - 1)), flags)
+        close(sig, g[f"naobj/{name}/sigmas"], 1e-6); close(w, g[f"naobj/{name}/weights"], 1e-6)
+        close(noisy, g[f"naobj/{name}/noisy_adjs"], 1e-6); close(noisy_x, g[f"naobj/{name}/noisy_nodes"], 1e-6)
+
+
+@pytest.mark.parametrize("name,regime,si,coin", __import__("tests.golden.cases", fromlist=["x"]).NODEADJ_TRAIN_CASES)
+def test_nodeadj_train_step_fingerprints(golden_nodeadj, golden_nodeadj_train, name, regime, si, coin):
+    """Autograd through the oracle reproduces the reference's losses and gradient fingerprints."""
+    import numpy as np
+    _, meta = golden_nodeadj
+    g = golden_nodeadj_train
+    c = NODEADJ_CASES[name]
+    sd = H.net_state(meta[f"keys/{name}"], c["seed"], regime)
+    flags, adj, node, sig, w, clean_a, clean_x = H.nodeadj_train_inputs(c, si)
+    with torch.enable_grad():
+        la, ln, grads = H.oracle_grads_nodeadj(sd, c["cfg"], adj, node, flags, sig, w, clean_a, clean_x, coin)
+    key = f"natrain/{name}/{regime}/s{si}/coin{int(coin)}"
+    assert np.allclose(la.numpy(), g[key + "/loss_adj"], rtol=1e-4) and np.allclose(ln.numpy(), g[key + "/loss_node"], rtol=1e-4)
+    names = [k for k, v in meta[f"keys/{name}"].items()]
+    order = [k for k in sd if k in grads]
+    total = float(torch.sqrt(sum((v.double() ** 2).sum() for v in grads.values())))
+    assert abs(total - float(g[key + "/grad_norm"])) <= 2e-4 * float(g[key + "/grad_norm"])
+    assert len(g[key + "/grad_abs_sums"]) == len(grads)
+    mine = np.sort(np.array([float(v.double().abs().sum()) for v in grads.values()]))
+    assert np.allclose(mine, np.sort(g[key + "/grad_abs_sums"]), rtol=2e-3, atol=1e-6 * total)
