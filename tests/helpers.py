@@ -151,3 +151,22 @@ def oracle_grads_nodeadj(sd, cfg, adj, node, flags, sig, w, clean_a, clean_x, co
         la, ln = nodeadj_loss(Da, Dn, clean_a, clean_x, flags, w)
         (la.mean() + ln.mean()).backward()
     return la.detach(), ln.detach(), {k: v.grad for k, v in leaves.items() if v.grad is not None}
+
+
+def synthetic_graphs(name, count, n_max, n_lo, n_hi, p_edge, seed):
+    """[count, n_max, n_max] 0/1 symmetric adjacency matrices of random graphs (filler-driven, reproducible)."""
+    flags = filler.node_flags(name + "/flags", count, n_max, n_lo, n_hi, seed)
+    u = filler.uniform(name + "/u", (count, n_max, n_max), seed)
+    a = torch.triu(((u + 1.0) * 0.5 < p_edge).float(), 1)
+    a = a + a.transpose(-1, -2)
+    return (a * flags[:, :, None] * flags[:, None, :]).numpy()
+
+
+def mmd_graph_sets(golden):
+    """Fixed (reference set, predicted set) pairs of binarised graphs for the MMD statistics."""
+    sets = {}
+    for case in ("ego60_8", "ego60_256"):
+        pred = golden[f"sampler/{case}/thresholded"].astype(np.float32)
+        sets[f"ref_sampler/{case}"] = (synthetic_graphs("testset", 6, pred.shape[-1], 4, 18, 0.3, 91), pred)
+    sets["synthetic"] = (synthetic_graphs("setA", 8, 20, 12, 20, 0.35, 92), synthetic_graphs("setB", 7, 20, 10, 20, 0.2, 93))
+    return sets

@@ -318,6 +318,21 @@ def test_edm_sampler(S, golden, golden_meta, name):
     sure = valid & (ref.abs() > 1e-2)
     assert float((thr == thr_ref)[sure].float().mean()) >= 0.999
     print(f"{name}: max err {err:.3g}, raw thresholded agreement {float((thr == thr_ref)[valid].float().mean()):.5f}")
+    # north star: "binarised-graph MMD statistics must match the reference's".  The reference's evaluation
+    # (evaluation/stats.py eval_torch_batch, degree / cluster / spectral) on ITS samples is in golden_mmd.npz; the same
+    # statistics (oracle/graph_stats.py, pinned to it) on OUR samples against the same test set must agree.
+    key = f"mmd/ref_sampler/{name}"
+    import os
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_mmd.npz"), allow_pickle=False) as z:
+        mmd_ref = z[key] if key in z.files else None
+    if mmd_ref is not None:
+        from oracle import graph_stats as GS
+        testset, _ = H.mmd_graph_sets(golden)[f"ref_sampler/{name}"]
+        r = GS.eval_adjs(testset, thr.numpy())
+        mine = np.array([r["degree"], r["cluster"], r["spectral"], r["average"]])
+        flips = int((thr != thr_ref)[valid].sum())
+        print(f"{name}: MMD ours {mine.round(6).tolist()} reference {mmd_ref.round(6).tolist()} ({flips} flipped entries)")
+        assert np.allclose(mine, mmd_ref, rtol=0, atol=(1e-9 if flips == 0 else 2e-2)), (mine, mmd_ref)
 
 
 # ---------------------------------------------------------------------------------------------
