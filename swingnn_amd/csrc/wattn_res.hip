@@ -1,4 +1,4 @@
-// Window-attention half of a Swin block for the NARROW stage (C = 96, 3 heads, 6x6 windows; swin_gnn.py:238-272):
+// Window-attention half of a Swin block for the NARROW stage (C = 96, 3 heads, 4x4 / 6x6 / 8x8 windows; swin_gnn.py:238-272):
 //     x1 = silu(shift + x (1 + scale));  x_out = x1 + proj( softmax(q k^T * hd^-1/2 + bias + mask) v ),  qkv = Wqkv LN1(x1)
 // Same per-window data flow and pinned fragment groups as wattn_ring.hip, but all weights of the block (3 heads x 24
 // fragments = 72 KiB) stay RESIDENT in LDS: persistent workgroups of 8 waves copy them once by LDS-DMA, then every
@@ -23,9 +23,12 @@ struct ResAttnArgs {
   int B, res, shift, heads;
 };
 
-template <int C, int NW, int AHEAD>
+template <int C, int NW, int AHEAD, int WIN>
 __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
-  constexpr int WIN = 6, NTOK = 36, NTM = 3, KSP = 2;
+  // window geometry: NTOK tokens in NTM 16-token MFMA tiles, KSP 32-deep k-steps over the keys; the last tile holds
+  // REM valid tokens (WIN = 6: 36 tokens = 3 tiles, REM 4; WIN = 8: 64 = 4 tiles; WIN = 4: 16 = 1 tile)
+  constexpr int NTOK = WIN * WIN, NTM = (NTOK + 15) / 16, KSP = (NTM + 1) / 2, REM = NTOK - (NTM - 1) * 16;
+  static_assert(WIN <= 8 && REM % 4 == 0, "in-window coordinates are packed in 3 bits; key padding is per lane group");
   constexpr int KS = C / 32;
   constexpr int NT = C / 16;
   constexpr int SLAB = 2 * KS;           // fragments per slab (== NT)
@@ -77,7 +80,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
   // key side: token j = kt*16 + 4*lg + r.  iyx / kyx hold the in-window coordinates, qrel - krel the byte offset
   // into a head's relative-position bias column (:110-121) ----
   int iyx[NTM], kyx[NTM], qrel[NTM], krel[NTM][4];
-  const float kpad = (lg == 0) ? 0.f : -3.0e38f;  // last key tile: keys 32 + 4*lg + r exist only for lg == 0
+  const float kpad = (4 * lg < REM) ? 0.f : -3.0e38f;  // last key tile: keys 4*lg + r exist only below REM
 #pragma unroll
   for (int mt = 0; mt < NTM; ++mt) {
     const int i = min(mt * 16 + l15, NTOK - 1);
@@ -381,30 +384,43 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
 }  // namespace
 
 bool wattn_res_supported(int C, int heads, int win, int res) {
-  return C == 96 && heads == 3 && win == 6 && res % 6 == 0;
+  return C == 96 && heads == 3 && (win == 4 || win == 6 || win == 8) && res % win == 0;
 }
+
+namespace {
+template <int WIN>
+int launch_res_t(const ResAttnArgs& a, int total, hipStream_t s) {
+  constexpr int C = 96, NW = 8, AHEAD = 3, NB = (2 * WIN - 1) * (2 * WIN - 1);
+  const size_t lds = (size_t)a.heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 +
+                     (size_t)(4 * C + NB * a.heads) * sizeof(float);
+  const int nwg = min(cdiv(total, NW), 256);
+  static bool attr_set = false;
+  if (!attr_set) {
+    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_res<C, NW, AHEAD, WIN>,
+                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    if (e != hipSuccess) return (int)e;
+    attr_set = true;
+  }
+  hipLaunchKernelGGL((k_wattn_res<C, NW, AHEAD, WIN>), dim3(nwg), dim3(64 * NW), lds, s, a);
+  return 0;
+}
+}  // namespace
 
 int launch_wattn_res(const swg_block* blk, int B, const float* x, const float* cond, int cond_stride, float* out,
                      hipStream_t s) {
   if (!wattn_res_supported(blk->C, blk->heads, blk->win, blk->res) || !blk->attn_img) return SWG_E_UNSUPPORTED;
-  constexpr int C = 96, NW = 8, AHEAD = 3;
+  constexpr int C = 96;
   const int nW = (blk->res / blk->win) * (blk->res / blk->win);
   ResAttnArgs a = {x, out, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, (const bf16*)blk->attn_img,
                    blk->qkv.b, blk->proj.b, blk->rpb, B, blk->res, blk->shift, blk->heads};
-  const size_t lds = (size_t)blk->heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 +
-                     (size_t)(4 * C + 121 * blk->heads) * sizeof(float);
   const int total = B * nW;
-  const int nwg = min(cdiv(total, NW), 256);
   const double T = (double)B * blk->res * blk->res;
-  SwgProfScope ps(KID_WATTN_RES, 8.0 * T * C * C + 4.0 * T * 36 * C, 8.0 * T * C + 8.0 * C * C, s);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_res<C, NW, AHEAD>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
-  hipLaunchKernelGGL((k_wattn_res<C, NW, AHEAD>), dim3(nwg), dim3(64 * NW), lds, s, a);
+  SwgProfScope ps(KID_WATTN_RES, 8.0 * T * C * C + 4.0 * T * (blk->win * blk->win) * C, 8.0 * T * C + 8.0 * C * C, s);
+  int r;
+  if (blk->win == 4) r = launch_res_t<4>(a, total, s);
+  else if (blk->win == 8) r = launch_res_t<8>(a, total, s);
+  else r = launch_res_t<6>(a, total, s);
+  if (r) return r;
   SWG_LAUNCH_CHECK();
   return 0;
 }

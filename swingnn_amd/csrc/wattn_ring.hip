@@ -1,4 +1,4 @@
-// Window-attention half of a Swin block (model/swin_gnn/swin_gnn.py:238-272), 6x6 windows, head_dim 32:
+// Window-attention half of a Swin block (model/swin_gnn/swin_gnn.py:238-272), 6x6 or 8x8 windows, head_dim 32:
 //     x1 = silu(shift + x (1 + scale));  x_out = x1 + proj( softmax(q k^T * hd^-1/2 + bias + mask) v ),  qkv = Wqkv LN1(x1)
 // window_partition / cyclic shift / window_reverse are pure addressing (gather list per window).
 //
@@ -48,9 +48,12 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN>
 __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
-  constexpr int WIN = 6, NTOK = 36, NTM = 3, KSP = 2;
+  // window geometry: NTOK tokens in NTM 16-token MFMA tiles, KSP 32-deep k-steps over the keys; the last tile holds
+  // REM valid tokens (WIN = 6: 36 tokens = 3 tiles, REM 4; WIN = 8: 64 tokens = 4 full tiles)
+  constexpr int NTOK = WIN * WIN, NTM = (NTOK + 15) / 16, KSP = (NTM + 1) / 2, REM = NTOK - (NTM - 1) * 16;
+  static_assert(REM % 4 == 0, "key padding is per lane group");
   constexpr int KS = C / 32;
   constexpr int NT = C / 16;
   constexpr int SLAB = 2 * KS;                       // fragments per slab (== NT)
@@ -216,7 +219,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) STAGE_PIECE(min(u, nunits - 1), u * UNIT_BYTES, i);
   int qrel[NTM], krel[NTM][4], rids[NTM];
-  const float kpad = (lg == 0) ? 0.f : -3.0e38f;  // last key tile: keys 32 + 4*lg + r exist only for lg == 0
+  const float kpad = (4 * lg < REM) ? 0.f : -3.0e38f;  // last key tile: keys 4*lg + r exist only below REM
 #pragma unroll
   for (int mt = 0; mt < NTM; ++mt) {
     int iy, ix, rid, tok;
@@ -494,24 +497,24 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   }
 }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN>
 int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
-  const size_t lds = (size_t)NBUF * 24 * 1024 + (size_t)(4 * C + 121 * a.heads) * sizeof(float);
+  const size_t lds = (size_t)NBUF * 24 * 1024 + (size_t)(4 * C + (2 * WIN - 1) * (2 * WIN - 1) * a.heads) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN>,
+    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>,
                                        hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
-  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN>), dim3(nwg), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>), dim3(nwg), dim3(256), lds, s, a);
   return 0;
 }
 
 }  // namespace
 
 bool wattn_ring_supported(int C, int heads, int win, int res) {
-  return (C == 192 || C == 384) && heads * 32 == C && win == 6 && res % 6 == 0;
+  return (C == 192 || C == 384) && heads * 32 == C && (win == 6 || win == 8) && res % win == 0;
 }
 bool wattn_ring_fuses_proj(int C) { return C != 384; }
 
@@ -532,10 +535,16 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   const int nwg = cdiv(B * nW, 4);
   const double T = (double)B * blk->res * blk->res;
   const double gemm = wattn_ring_fuses_proj(C) ? 8.0 : 6.0;
-  SwgProfScope ps(KID_WATTN_RING, gemm * T * C * C + 4.0 * T * 36 * C, (gemm == 8.0 ? 8.0 : 6.0) * T * C + gemm * C * C, s);
+  SwgProfScope ps(KID_WATTN_RING, gemm * T * C * C + 4.0 * T * (blk->win * blk->win) * C,
+                  (gemm == 8.0 ? 8.0 : 6.0) * T * C + gemm * C * C, s);
   int r;
-  if (C == 192) r = launch_t<192, true, 4, 1, 5, true>(a, nwg, s);
-  else r = launch_t<384, false, 5, 1, 5, true>(a, nwg, s);
+  if (blk->win == 8) {
+    if (C == 192) r = launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s);
+    else r = launch_t<384, false, 5, 1, 5, true, 8>(a, nwg, s);
+  } else {
+    if (C == 192) r = launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s);
+    else r = launch_t<384, false, 5, 1, 5, true, 6>(a, nwg, s);
+  }
   if (r) return r;
   SWG_LAUNCH_CHECK();
   return 0;

@@ -185,8 +185,11 @@ def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse
 def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
     img = None
     aimg = None
-    if (USE_FUSED_ATTN and blk.dim in RING_ATTN_FUSED_PROJ and blk.window_size == 6
-            and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % 6 == 0):
+    # fused attention geometries (csrc/wattn_res.hip: C = 96, windows 4 / 6 / 8; csrc/wattn_ring.hip: C = 192 / 384,
+    # windows 6 / 8); the weight image does not depend on the window size
+    wins = (4, 6, 8) if blk.dim == 96 else (6, 8)
+    if (USE_FUSED_ATTN and blk.dim in RING_ATTN_FUSED_PROJ and blk.window_size in wins
+            and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % blk.window_size == 0):
         aimg = _ptr(keep(wattn_ring_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads,
                                           RING_ATTN_FUSED_PROJ[blk.dim])))
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
