@@ -80,6 +80,12 @@ class EDMSampler(GeneralSampler):
         self.sigma_deriv = lambda t: torch.ones_like(torch.as_tensor(t))
         self.s = lambda t: 1
         self.s_deriv = lambda t: 0
+        # Opt-in (not a reference option): let swingnn_amd.Precond reuse network passes inside a Heun step.  Both model
+        # calls of a step see the same (x_hat, sigma_hat) and Precond discards the passed self_cond, so a step needs at
+        # most 2 distinct passes instead of 2 + (number of coins that came up): expected 1.75 instead of 3 per step, the
+        # samples are bit-identical (tests/test_gpu_parity.py::test_pass_reuse_is_bit_identical).  Off by default so that
+        # the default run executes every network pass the reference executes.
+        self.reuse_passes = False
 
     # overridable so that parity tests can inject pre-drawn noise
     def _randn_like(self, x):
@@ -127,8 +133,11 @@ class EDMSampler(GeneralSampler):
         x_next = (E._as_f32(init_adjs) * float(self.sigma_steps[0].to(torch.float32))).contiguous()
         x_hat, x_prime, d_cur = torch.empty_like(x_next), torch.empty_like(x_next), torch.empty_like(x_next)
         x_self_cond = None
+        reuse = bool(self.reuse_passes and masked_model and gt is None and hasattr(inner, "_step_memo"))
         for i, (t_hat, coef, h, t_prime) in enumerate(consts):
             x_cur = x_next
+            if reuse:
+                inner._step_memo = {}
             raw = self._randn_like(x_cur)
             L.check(lib.swg_heun_churn(B, N, x_cur.data_ptr(), raw.data_ptr(), flags.data_ptr(), coef,
                                        x_hat.data_ptr(), sp()), "swg_heun_churn")
@@ -155,6 +164,8 @@ class EDMSampler(GeneralSampler):
                                              den.data_ptr(), flags.data_ptr(), t_prime, h, x_next.data_ptr(), sp()),
                         "swg_heun_correct")
             x_self_cond = den if self.self_condition else None
+            if reuse:
+                inner._step_memo = None
             L.check(lib.swg_sym_check(B, N, x_next.data_ptr(), sym_acc.data_ptr(), sp()), "swg_sym_check")
             if flag_interim_adjs and i in snaps:
                 adjs_ls.append(x_next.cpu())

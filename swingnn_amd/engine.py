@@ -346,9 +346,14 @@ def _as_f32(t: torch.Tensor) -> torch.Tensor:
     return t if t.is_contiguous() else t.contiguous()
 
 
+PASS_COUNT = 0  # network passes launched through network_pass (reported by bench.py)
+
+
 def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_uniform: bool, self_cond, out=None,
                  sym_err=None):
     """One pass of the network through swg_precond_forward (mode 0: SwinGNN.forward, mode 1: Precond core)."""
+    global PASS_COUNT
+    PASS_COUNT += 1
     x = _as_f32(x)
     flags = _as_f32(node_flags)
     labels = _as_f32(labels)

@@ -28,6 +28,7 @@ class Precond(nn.Module):
         self.self_condition = self_condition
         self.symmetry_check = 'deferred'
         self._sym_acc = None
+        self._step_memo = None  # set by EDMSampler(reuse_passes=True) for the duration of one Heun step
 
     def _acc(self, device):
         if self._sym_acc is None or self._sym_acc.device != device:
@@ -43,9 +44,27 @@ class Precond(nn.Module):
         labels = sigmas[:1] if uniform else sigmas
         cache = E.get_cache(self.model)
         sc = None  # the argument is discarded, precond.py:39
-        if self.self_condition and np.random.rand() < 0.5:
-            sc = E.network_pass(cache, 1, x, node_flags, labels, uniform, None)
+        coin = bool(self.self_condition and np.random.rand() < 0.5)
         acc = None if self.symmetry_check == 'off' else self._acc(x.device)
+        memo = None if with_grad else self._step_memo
+        if memo is not None:
+            # Both model calls of a Heun step evaluate the SAME (x_hat, sigma_hat) (mcmc_sampler/edm.py:183,205) and the
+            # passed self_cond is discarded, so the step only ever needs P0 = D(x_hat | no self-cond) and, when a coin
+            # comes up, P1 = D(x_hat | self-cond = P0).  The kernels are deterministic: reusing a pass is bit-identical
+            # to recomputing it.  The coin is still drawn once per call, so the numpy stream stays aligned.
+            if memo.get("key") != (x.data_ptr(), tuple(x.shape)):
+                memo.clear()
+                memo["key"] = (x.data_ptr(), tuple(x.shape))
+            sc_on = self.model.self_condition
+            if "P0" not in memo:
+                memo["P0"] = E.network_pass(cache, 1, x, node_flags, labels, uniform, None, sym_err=acc)
+            if not (coin and sc_on):
+                return memo["P0"]
+            if "P1" not in memo:
+                memo["P1"] = E.network_pass(cache, 1, x, node_flags, labels, uniform, memo["P0"], sym_err=acc)
+            return memo["P1"]
+        if coin:
+            sc = E.network_pass(cache, 1, x, node_flags, labels, uniform, None)
         if with_grad:  # training step (runner/trainer/trainer.py:110): forward that keeps op inputs + HIP backward
             from .train import denoise_with_grad
             D = denoise_with_grad(self.model, 1, x, node_flags, sigmas.expand(x.shape[0]) if uniform else sigmas,

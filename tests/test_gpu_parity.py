@@ -335,6 +335,32 @@ def test_edm_sampler(S, golden, golden_meta, name):
         assert np.allclose(mine, mmd_ref, rtol=0, atol=(1e-9 if flips == 0 else 2e-2)), (mine, mmd_ref)
 
 
+def test_pass_reuse_is_bit_identical(S, golden_meta):
+    """EDMSampler.reuse_passes (opt-in): both model calls of a Heun step evaluate the same (x_hat, sigma_hat), so the
+    sampler may reuse P0 / P1 inside a step.  Same seeds -> the samples must be bit-identical to the default run, with
+    fewer network passes (expected 1.75 instead of 3 per two-call step)."""
+    from swingnn_amd import engine as E
+    for net_name, steps, B in (("ego60", 24, 3), ("grid192", 3, 1)):
+        nc = NET_CASES[net_name]
+        cfg = nc["cfg"]
+        pre = build_precond(S, net_name, golden_meta, "init", seed=7)
+        flags = filler.node_flags("flags", B, cfg["img_size"], nc["n_lo"], nc["n_hi"], 7).to(DEV)
+        outs, counts = [], []
+        for reuse in (False, True):
+            smp = S.EDMSampler(num_steps=steps, clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
+                               clip_samples_scope="x_0", self_condition=cfg["self_condition"], dev=DEV)
+            smp.reuse_passes = reuse
+            torch.manual_seed(11)
+            torch.cuda.manual_seed(11)
+            np.random.seed(11)
+            n0 = E.PASS_COUNT
+            outs.append(smp.sample(pre, flags))
+            counts.append(E.PASS_COUNT - n0)
+        assert torch.equal(outs[0], outs[1]), f"{net_name}: max diff {float((outs[0] - outs[1]).abs().max())}"
+        assert counts[1] < counts[0] and counts[1] <= 2 * steps - 1 + 1
+        print(f"{net_name}: {counts[0]} passes by default, {counts[1]} with reuse ({steps} Heun steps)")
+
+
 # ---------------------------------------------------------------------------------------------
 def test_objective_and_loss(S, golden):
     """Rows a18/a19: training objective (noisy input, sigmas, weights, preconditioning scalars) and loss, forward."""
