@@ -47,15 +47,27 @@ __global__ __launch_bounds__(256) void k_transpose_bf16(const T* __restrict__ sr
 }
 
 // ---- out[n] += sum_m src[m][n] ----
+// 64 columns x 4 row phases per workgroup (narrow matrices keep all 256 threads busy), rpb rows per workgroup,
+// one atomic per column and workgroup
 template <typename T>
 __global__ __launch_bounds__(256) void k_colsum(const T* __restrict__ src, int M, int N, int ld, int rpb,
                                                 float* __restrict__ out) {
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= N) return;
+  __shared__ float part[4][64];
+  const int cx = threadIdx.x & 63, ry = threadIdx.x >> 6;
+  const int n = blockIdx.x * 64 + cx;
   const int r0 = blockIdx.y * rpb, r1 = min(M, r0 + rpb);
-  float s = 0.f;
-  for (int m = r0; m < r1; ++m) s += (float)src[(size_t)m * ld + n];
-  atomicAdd(out + n, s);
+  float s0 = 0.f, s1 = 0.f;
+  if (n < N) {
+    int m = r0 + ry;
+    for (; m + 4 < r1; m += 8) {
+      s0 += (float)src[(size_t)m * ld + n];
+      s1 += (float)src[(size_t)(m + 4) * ld + n];
+    }
+    if (m < r1) s0 += (float)src[(size_t)m * ld + n];
+  }
+  part[ry][cx] = s0 + s1;
+  __syncthreads();
+  if (ry == 0 && n < N) atomicAdd(out + n, (part[0][cx] + part[1][cx]) + (part[2][cx] + part[3][cx]));
 }
 
 // ---- GELU (exact erf form, swin_gnn.py:10,15) on the bf16 hidden buffer, forward and derivative ----
@@ -339,12 +351,12 @@ int launch_transpose_bf16(const bf16* src, int M, int N, int ld, bf16* dst, int 
   return 0;
 }
 
-static inline int colsum_rpb(int M) { return max(64, cdiv(M, 256)); }
+static inline int colsum_rpb(int M) { return max(64, min(1024, cdiv(M, 256))); }
 int launch_colsum_f32(const float* src, int M, int N, int ld, float* out, hipStream_t s) {
   if (M <= 0 || N <= 0) return 0;
   const int rpb = colsum_rpb(M);
   SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)M * N * 4.0, s);
-  hipLaunchKernelGGL((k_colsum<float>), dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, s, src, M, N, ld, rpb, out);
+  hipLaunchKernelGGL((k_colsum<float>), dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, s, src, M, N, ld, rpb, out);
   SWG_LAUNCH_CHECK();
   return 0;
 }
@@ -352,7 +364,7 @@ int launch_colsum_bf16(const bf16* src, int M, int N, int ld, float* out, hipStr
   if (M <= 0 || N <= 0) return 0;
   const int rpb = colsum_rpb(M);
   SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)M * N * 2.0, s);
-  hipLaunchKernelGGL((k_colsum<bf16>), dim3(cdiv(N, 256), cdiv(M, rpb)), dim3(256), 0, s, src, M, N, ld, rpb, out);
+  hipLaunchKernelGGL((k_colsum<bf16>), dim3(cdiv(N, 64), cdiv(M, rpb)), dim3(256), 0, s, src, M, N, ld, rpb, out);
   SWG_LAUNCH_CHECK();
   return 0;
 }

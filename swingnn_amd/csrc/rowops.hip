@@ -334,10 +334,66 @@ __global__ __launch_bounds__(256) void k_gemv_rows(const float* __restrict__ W, 
   }
 }
 
+// The same product for a whole training batch (per-sample sigmas: Bx = B rows): fp32 LDS-tiled GEMM, 64 (rows) x 64
+// (features) per workgroup, BK = 16, 4 x 4 outputs per thread.  Exact fp32 like the GEMV (the conditioning vectors
+// scale every block's residual stream, so they do not go through bf16).
+__global__ __launch_bounds__(256) void k_linear_f32_tiled(const float* __restrict__ W, const float* __restrict__ bias,
+                                                          const float* __restrict__ x, int Bx, int N, int K, int act,
+                                                          float* __restrict__ out) {
+  __shared__ __attribute__((aligned(16))) float sX[16][68];
+  __shared__ __attribute__((aligned(16))) float sW[16][68];
+  const int tid = threadIdx.x, tx = tid & 15, ty = tid >> 4;
+  const int n0 = blockIdx.x * 64, b0 = blockIdx.y * 64;
+  const int lrow = tid >> 2, lk = (tid & 3) * 4;
+  const float* xr = x + (size_t)min(b0 + lrow, Bx - 1) * K + lk;
+  const float* wr = W + (size_t)min(n0 + lrow, N - 1) * K + lk;
+  float acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = 0.f;
+  for (int k0 = 0; k0 < K; k0 += 16) {
+    const float4 xv = *reinterpret_cast<const float4*>(xr + k0);
+    const float4 wv = *reinterpret_cast<const float4*>(wr + k0);
+    sX[lk + 0][lrow] = xv.x; sX[lk + 1][lrow] = xv.y; sX[lk + 2][lrow] = xv.z; sX[lk + 3][lrow] = xv.w;
+    sW[lk + 0][lrow] = wv.x; sW[lk + 1][lrow] = wv.y; sW[lk + 2][lrow] = wv.z; sW[lk + 3][lrow] = wv.w;
+    __syncthreads();
+#pragma unroll
+    for (int kk = 0; kk < 16; ++kk) {
+      const float4 a = *reinterpret_cast<const float4*>(&sX[kk][4 * ty]);
+      const float4 w = *reinterpret_cast<const float4*>(&sW[kk][4 * tx]);
+      const float av[4] = {a.x, a.y, a.z, a.w}, wv4[4] = {w.x, w.y, w.z, w.w};
+#pragma unroll
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = fmaf(av[i], wv4[j], acc[i][j]);
+    }
+    __syncthreads();
+  }
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int b = b0 + 4 * ty + i;
+    if (b >= Bx) continue;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = n0 + 4 * tx + j;
+      if (n >= N) continue;
+      float v = acc[i][j] + (bias ? bias[n] : 0.f);
+      if (act == 1) v = silu_f(v);
+      out[(size_t)b * N + n] = v;
+    }
+  }
+}
+
 int launch_gemv_rows(const float* W, const float* bias, const float* x, int Bx, int N, int K, int act, float* out,
                      hipStream_t s) {
   if (K % 4 || K > 512) return SWG_E_UNSUPPORTED;
   SwgProfScope ps(KID_GEMV, 2.0 * Bx * (double)N * K, 4.0 * N * (double)K + 4.0 * Bx * (K + N), s);
+  if (Bx >= 16 && K % 16 == 0) {
+    hipLaunchKernelGGL(k_linear_f32_tiled, dim3(cdiv(N, 64), cdiv(Bx, 64)), dim3(256), 0, s, W, bias, x, Bx, N, K, act, out);
+    SWG_LAUNCH_CHECK();
+    return 0;
+  }
   hipLaunchKernelGGL(k_gemv_rows, dim3(cdiv(N, 4)), dim3(256), 0, s, W, bias, x, Bx, N, K, act, out);
   SWG_LAUNCH_CHECK();
   return 0;

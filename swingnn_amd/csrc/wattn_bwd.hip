@@ -22,6 +22,7 @@ struct WbArgs {
   float* drpb;
   int B, res, win, shift, heads, C, hd;
   float scale;
+  int nr;  // LDS tile rows: ceil16(win * win)
 };
 
 constexpr int HDP = 32;     // padded head dim
@@ -52,13 +53,16 @@ __device__ __forceinline__ void store_row(bf16* p, int hd, const float* r, float
 
 __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
   extern __shared__ __attribute__((aligned(16))) float sm[];
+  // rows of the per-window tiles: NR = ceil16(tokens per window), so that small windows (4x4: 9 KB instead of 66 KB)
+  // leave room for many workgroups per CU
+  const int NR = a.nr;
   float* Ks = sm;
-  float* Vs = Ks + 64 * HDP;
-  float* Qs = Vs + 64 * HDP;
-  float* Ds = Qs + 64 * HDP;
-  float* Pm = Ds + 64 * HDP;
-  float* Sm = Pm + 64 * PLD;
-  float* bias = Sm + 64 * PLD;
+  float* Vs = Ks + NR * HDP;
+  float* Qs = Vs + NR * HDP;
+  float* Ds = Qs + NR * HDP;
+  float* Pm = Ds + NR * HDP;
+  float* Sm = Pm + NR * PLD;
+  float* bias = Sm + NR * PLD;
   float* dbias = bias + NBMAX;
   int* rid = reinterpret_cast<int*>(dbias + NBMAX);
 
@@ -96,13 +100,15 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
       float t[HDP];
       const bf16* row = a.qkv + tok * a.ldq + hc;
       load_row(row, act ? a.hd : 0, q);
-      put_row(Qs + lane * HDP, q);
-      load_row(row + a.C, act ? a.hd : 0, t);
-      put_row(Ks + lane * HDP, t);
-      load_row(row + 2 * a.C, act ? a.hd : 0, t);
-      put_row(Vs + lane * HDP, t);
       load_row(a.dO + tok * a.ldo + hc, act ? a.hd : 0, go);
-      put_row(Ds + lane * HDP, go);
+      if (lane < NR) {
+        put_row(Qs + lane * HDP, q);
+        load_row(row + a.C, act ? a.hd : 0, t);
+        put_row(Ks + lane * HDP, t);
+        load_row(row + 2 * a.C, act ? a.hd : 0, t);
+        put_row(Vs + lane * HDP, t);
+        put_row(Ds + lane * HDP, go);
+      }
     }
     __syncthreads();
 
@@ -202,11 +208,13 @@ int launch_wattn_bwd(const bf16* qkv, int ldq, const bf16* dO, int ldo, int B, i
   if (n > 64 || hd > 32 || hd % 4 || ldq % 4 || ldo % 4 || lddq % 4 || C % 4 || win > 8) return SWG_E_UNSUPPORTED;
   if (shift < 0 || shift >= win) return SWG_E_SHAPE;
   if (!qkv || !dO || !dqkv || !rpb || !drpb) return SWG_E_NULL;
-  WbArgs a = {qkv, ldq, dO, ldo, dqkv, lddq, rpb, drpb, B, res, win, shift, heads, C, hd, 1.0f / sqrtf((float)hd)};
-  const size_t lds = (size_t)(4 * 64 * HDP + 2 * 64 * PLD + 2 * NBMAX + 64) * sizeof(float);
+  const int nr = round_up(n, 16);
+  WbArgs a = {qkv, ldq, dO, ldo, dqkv, lddq, rpb, drpb, B, res, win, shift, heads, C, hd, 1.0f / sqrtf((float)hd), nr};
+  const size_t lds = (size_t)(4 * nr * HDP + 2 * nr * PLD + 2 * NBMAX + 64) * sizeof(float);
+  const size_t lds_max = (size_t)(4 * 64 * HDP + 2 * 64 * PLD + 2 * NBMAX + 64) * sizeof(float);
   static bool attr_set = false;
   if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
+    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
     if (e != hipSuccess) return (int)e;
     attr_set = true;
   }
