@@ -372,6 +372,24 @@ int swg_adam_ema_step(const void* p_ptrs, const void* g_ptrs, const int32_t* num
                       float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                       void* stream);
 
+/* ---- derived-operand refresh (no counterpart in the reference, which reads the fp32 parameters directly) ---- *
+ * After an optimizer step every bf16 operand derived from the fp32 nn.Parameters (K-padded copies, transposed copies
+ * for the backward GEMMs, fragment-order images of the fused kernels) is rewritten IN PLACE by one launch, so the
+ * descriptors above stay valid.  items / chunk tables are DEVICE arrays.  Chunk c works on item chunk_item[c]:
+ *   mode 0  gather : dst[i] = idx[i] == 0 ? 0 : concat(src0[0..n0), src1)[idx[i] - 1], i in [16384 c0, 16384 (c0+1)) < count
+ *   mode 1  pad    : dst [N, ld] = src0 [N, K] with zero columns K..ld,             same linear chunking over N*ld
+ *   mode 2  padT   : dst [K, ld] = src0 [N, K] transposed with zero columns N..ld,   64 x 64 tile (c0: k block, c1: n block) */
+typedef struct swg_refresh_item {
+  const float* src0;
+  const float* src1;
+  void* dst;          /* bf16 */
+  const int32_t* idx; /* mode 0 */
+  int32_t mode, n0, N, K, ld, pad_;
+  int64_t count;
+} swg_refresh_item;
+int swg_refresh_derived(const swg_refresh_item* items, const int32_t* chunk_item, const int32_t* chunk_c0,
+                        const int32_t* chunk_c1, int32_t n_chunks, void* stream);
+
 /* ---- measurement aid (no counterpart in the reference) ---------------------------------- *
  * When enabled, every internal kernel launch is bracketed by HIP events on its stream and its
  * algorithmic FLOPs / bytes are tallied per kernel.  swg_prof_read synchronises the recorded events.

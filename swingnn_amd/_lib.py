@@ -93,6 +93,11 @@ class SwgNodeAdjTrain(C.Structure):
                 ("norm", SwgLnTrain)]
 
 
+class SwgRefreshItem(C.Structure):
+    _fields_ = [("src0", _fp), ("src1", _fp), ("dst", _fp), ("idx", _fp), ("mode", C.c_int32), ("n0", C.c_int32),
+                ("N", C.c_int32), ("K", C.c_int32), ("ld", C.c_int32), ("pad_", C.c_int32), ("count", C.c_int64)]
+
+
 # every symbol include/swingnn_hip.h declares: name -> (restype, argtypes)
 _i32, _sz, _f = C.c_int32, C.c_size_t, C.c_float
 SYMBOLS = {
@@ -149,6 +154,7 @@ SYMBOLS = {
     "swg_grad_sqnorm": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _fp, _fp]),
     "swg_adam_ema_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _fp, _fp, _fp, C.c_int64, _i32,
                                     C.POINTER(C.c_float), _fp, _f, _f, _f, _f, _f, _f, _i32, _fp]),
+    "swg_refresh_derived": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _fp]),
     "swg_prof_enable": (C.c_int, [_i32]),
     "swg_prof_reset": (C.c_int, []),
     "swg_prof_kernels": (C.c_int, []),

@@ -127,3 +127,63 @@ int swg_adam_ema_step(const void* p_ptrs, const void* g_ptrs, const int32_t* num
 int swg_optim_chunk(void) { return CHUNK; }
 
 }  // extern "C"
+
+// ------------------------------------------------------------------------------------------------------------------
+// Refresh of the DERIVED weight operands after an optimizer step (no counterpart in the reference: the reference's
+// kernels read the fp32 nn.Parameters directly).  One launch rewrites every bf16 operand the kernels consume from the
+// fp32 parameters: K-padded copies, transposed copies (backward) and the fragment-order images of the fused kernels
+// (gather through a precomputed index map).  Table-driven like the optimizer kernels above.
+// ------------------------------------------------------------------------------------------------------------------
+namespace {
+
+__global__ __launch_bounds__(256) void k_refresh_derived(const swg_refresh_item* __restrict__ items,
+                                                         const int32_t* __restrict__ chunk_item,
+                                                         const int32_t* __restrict__ chunk_c0,
+                                                         const int32_t* __restrict__ chunk_c1) {
+  __shared__ float tile[64][65];
+  const swg_refresh_item it = items[chunk_item[blockIdx.x]];
+  const int c0 = chunk_c0[blockIdx.x], c1 = chunk_c1[blockIdx.x];
+  __bf16* dst = reinterpret_cast<__bf16*>(it.dst);
+  if (it.mode == 2) {  // dst[k, n] (row stride ld) = src[n, k], zero for n >= N; tile (c0: k block, c1: n block)
+    const int k0 = c0 * 64, n0 = c1 * 64;
+    const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+    for (int j = ty; j < 64; j += 4) {
+      const int n = n0 + j, k = k0 + tx;
+      tile[j][tx] = (n < it.N && k < it.K) ? it.src0[(size_t)n * it.K + k] : 0.f;
+    }
+    __syncthreads();
+    for (int i = ty; i < 64; i += 4) {
+      const int k = k0 + i, n = n0 + tx;
+      if (k < it.K && n < it.ld) dst[(size_t)k * it.ld + n] = (__bf16)tile[tx][i];
+    }
+    return;
+  }
+  const int64_t base = (int64_t)c0 * 16384;
+  const int64_t end = base + 16384 < it.count ? base + 16384 : it.count;
+  if (it.mode == 1) {  // dst[n, k] (row stride ld) = src[n, k], zero for k >= K
+    for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+      const int n = (int)(i / it.ld), k = (int)(i - (int64_t)n * it.ld);
+      dst[i] = (__bf16)(k < it.K ? it.src0[(size_t)n * it.K + k] : 0.f);
+    }
+    return;
+  }
+  // mode 0: gather; idx value v: 0 = zero, otherwise element v-1 of the concatenation (src0 [n0] | src1)
+  for (int64_t i = base + threadIdx.x; i < end; i += 256) {
+    const int v = it.idx[i];
+    float x = 0.f;
+    if (v > 0) x = (v - 1 < it.n0) ? it.src0[v - 1] : it.src1[v - 1 - it.n0];
+    dst[i] = (__bf16)x;
+  }
+}
+
+}  // namespace
+
+extern "C" int swg_refresh_derived(const swg_refresh_item* items, const int32_t* chunk_item, const int32_t* chunk_c0,
+                                   const int32_t* chunk_c1, int32_t n_chunks, void* stream) {
+  if (n_chunks <= 0) return 0;
+  if (!items || !chunk_item || !chunk_c0 || !chunk_c1) return SWG_E_NULL;
+  hipLaunchKernelGGL(k_refresh_derived, dim3(n_chunks), dim3(256), 0, (hipStream_t)stream, items, chunk_item, chunk_c0,
+                     chunk_c1);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}

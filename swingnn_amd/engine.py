@@ -54,12 +54,31 @@ def _f32(t: torch.Tensor) -> torch.Tensor:
 class Keep:
     """Collects the tensors / ctypes objects a descriptor points into."""
 
-    def __init__(self):
+    def __init__(self, registry=None):
         self.items = []
+        # when not None: every derived bf16 operand is recorded as (mode, sources, dst[, idx]) so that it can be
+        # rewritten in place after an optimizer step (RefreshTable / swg_refresh_derived)
+        self.registry = registry
 
     def __call__(self, obj):
         self.items.append(obj)
         return obj
+
+    def image(self, fn, srcs, *args):
+        """A fragment-order image fn(*srcs, *args) of one or two weights.  Registered as a gather: the index map is
+        fn evaluated on element numbers (the builders only permute / gather / zero-pad, exact in fp32 below 2^24)."""
+        img = self(fn(*srcs, *args))
+        if self.registry is not None:
+            off, fake = 1, []
+            for w in srcs:
+                n = w.numel()
+                assert off + n < (1 << 24)
+                fake.append(torch.arange(off, off + n, dtype=torch.float32, device=w.device).view(w.shape))
+                off += n
+            idx = self(fn(*fake, *args, dtype=torch.float32).round().to(torch.int32).contiguous())
+            assert idx.shape == img.shape
+            self.registry.append(("gather", tuple(srcs), img, idx))
+        return img
 
     def f32(self, t):
         return _ptr(self(_f32(t)))
@@ -71,10 +90,59 @@ class Keep:
         wb = torch.zeros((N, Kp), dtype=torch.bfloat16, device=w.device)
         wb[:, :K] = w
         self(wb)
+        if self.registry is not None:
+            self.registry.append(("pad", (weight,), wb, None))
         return L.SwgLin(_ptr(wb), None if bias is None else self.f32(bias), N, K, Kp)
 
     def ln(self, mod) -> L.SwgLn:
         return L.SwgLn(self.f32(mod.weight), self.f32(mod.bias))
+
+
+class RefreshTable:
+    """Device tables for swg_refresh_derived built from a Keep registry: one launch rewrites every registered bf16
+    operand from the current fp32 parameters."""
+
+    CHUNK = 16384
+
+    def __init__(self, registry, device):
+        items = (L.SwgRefreshItem * max(len(registry), 1))()
+        ci, c0, c1 = [], [], []
+        self.keep = []
+        for k, (mode, srcs, dst, idx) in enumerate(registry):
+            w = srcs[0]
+            if any((not t.is_contiguous()) or t.dtype != torch.float32 for t in srcs):
+                raise NotImplementedError("derived operands are refreshed from contiguous fp32 parameters")
+            if mode == "gather":
+                n0 = w.numel()
+                items[k] = L.SwgRefreshItem(w.data_ptr(), srcs[1].data_ptr() if len(srcs) > 1 else None, dst.data_ptr(),
+                                            idx.data_ptr(), 0, n0, 0, 0, 0, 0, dst.numel())
+                n = (dst.numel() + self.CHUNK - 1) // self.CHUNK
+                ci += [k] * n; c0 += list(range(n)); c1 += [0] * n
+                self.keep.append(idx)
+            elif mode == "pad":      # dst [N, ld] <- w viewed as [N, K]
+                N, ld = dst.shape
+                K = w.numel() // N
+                items[k] = L.SwgRefreshItem(w.data_ptr(), None, dst.data_ptr(), None, 1, 0, N, K, ld, 0, dst.numel())
+                n = (dst.numel() + self.CHUNK - 1) // self.CHUNK
+                ci += [k] * n; c0 += list(range(n)); c1 += [0] * n
+            else:                    # "padT": dst [K, ld] <- w [N, K] transposed
+                N, K = w.shape
+                ld = dst.shape[1]
+                items[k] = L.SwgRefreshItem(w.data_ptr(), None, dst.data_ptr(), None, 2, 0, N, K, ld, 0, dst.numel())
+                tk, tn = (K + 63) // 64, (ld + 63) // 64
+                for a in range(tk):
+                    ci += [k] * tn; c0 += [a] * tn; c1 += list(range(tn))
+            self.keep += list(srcs) + [dst]
+        raw = torch.frombuffer(bytearray(bytes(items)), dtype=torch.uint8)
+        self.items = raw.to(device)
+        i32 = dict(dtype=torch.int32, device=device)
+        self.ci, self.c0, self.c1 = torch.tensor(ci, **i32), torch.tensor(c0, **i32), torch.tensor(c1, **i32)
+        self.n_chunks = len(ci)
+
+    def run(self):
+        if self.n_chunks:
+            L.check(L.lib.swg_refresh_derived(self.items.data_ptr(), self.ci.data_ptr(), self.c0.data_ptr(),
+                                              self.c1.data_ptr(), self.n_chunks, stream_ptr()), "swg_refresh_derived")
 
 
 FUSED_MLP_DIMS = (96,)
@@ -91,7 +159,7 @@ def _slot_swizzle(t: torch.Tensor) -> torch.Tensor:
     return torch.gather(t, -2, idx[:, :, None].expand(*t.shape[:-3], rows, 4, 8))
 
 
-def mlp_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
+def mlp_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
     """Weight image of the fused MLP kernel (csrc/mlp_fused.hip): per 64-wide hidden chunk, the fc1 rows
     [64, C] as [k-step][row][4 slots][8] followed by the fc2 columns [C, 64] as [k-step][row][4 slots][8] with
     the k order the fc1 accumulators imply (and the fc2 rows permuted, see below): element e of chunk ch is hidden 32*s + (4ch+e if e<4 else 16+4ch+e-4)."""
@@ -110,13 +178,13 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor) -> torch.Tensor:
     rho = 32 * (nt // 2) + 8 * (i // 4) + 4 * (nt % 2) + (i % 4)
     b = w2[rho].reshape(Cdim, nch, 2, 32)[..., pi].reshape(Cdim, nch, 2, 4, 8).permute(1, 2, 0, 3, 4)  # [hc, s2, row, ch, e]
     b = _slot_swizzle(b.contiguous()).reshape(nch, -1)
-    return torch.cat([a, b], dim=1).to(torch.bfloat16).contiguous()
+    return torch.cat([a, b], dim=1).to(dtype).contiguous()
 
 
 STREAM_MLP_HC = {384: 32, 192: 64}  # hidden chunk width of csrc/mlp_stream.hip per channel count
 
 
-def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int) -> torch.Tensor:
+def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int, dtype=torch.bfloat16) -> torch.Tensor:
     """Weight image of csrc/mlp_stream.hip, in MFMA fragment order (1 KiB = 64 lanes x 8 bf16 per fragment, lane
     16*lg + i holds row i, k-slots 8*lg .. 8*lg+7).  Image chunk j (j = 0 .. 4C/hc + 1) is
       [fc1 rows of hidden chunk j   as fragments (k-step, hidden tile)]
@@ -133,7 +201,7 @@ def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int) -> torch.Tenso
     b = b.permute(2, 3, 0, 4, 1, 5).reshape(nch, -1)
     z = torch.zeros(2, a.shape[1], device=dev)
     img = torch.cat([torch.cat([a, z], 0), torch.cat([z, b], 0)], dim=1)  # [nch + 2, W1 part | W2 part]
-    return img.to(torch.bfloat16).contiguous()
+    return img.to(dtype).contiguous()
 
 
 USE_FUSED_ATTN = True
@@ -159,7 +227,8 @@ def _pi(device) -> torch.Tensor:
 RING_ATTN_FUSED_PROJ = {96: True, 192: True, 384: False}  # 96: wattn_res.hip (weights resident in LDS)  # csrc/wattn_ring.hip geometries
 
 
-def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse_proj: bool) -> torch.Tensor:
+def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse_proj: bool,
+                     dtype=torch.bfloat16) -> torch.Tensor:
     """Weight stream of csrc/wattn_ring.hip (head_dim 32) as 1-KiB MFMA fragments (lane 16*lg + i holds row i,
     k-slots 8lg..8lg+7): per head the slabs Wv, Wq, Wk (rows [32, C]) as [k-step][16-row half][lane][8] and, when the
     projection is fused, the Wproj column slice [C, 32] as [out tile][lane][8] with rows in rho order and the
@@ -177,9 +246,9 @@ def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse
     if fuse_proj:
         w = wp[_rho(Cdim, dev)].reshape(Cdim // 16, 16, heads, 4, 8)                # [nt, i, h, lg, e]
         slabs.append(w.permute(2, 0, 3, 1, 4).reshape(heads, -1))                   # [h, (nt, lg, i, e)]
-        return torch.stack(slabs, dim=1).reshape(-1).to(torch.bfloat16).contiguous()
+        return torch.stack(slabs, dim=1).reshape(-1).to(dtype).contiguous()
     img = torch.stack(slabs, dim=1).reshape(-1)
-    return torch.cat([img, wp.reshape(-1)]).to(torch.bfloat16).contiguous()
+    return torch.cat([img, wp.reshape(-1)]).to(dtype).contiguous()
 
 
 def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
@@ -190,12 +259,12 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
     wins = (4, 6, 8) if blk.dim == 96 else (6, 8)
     if (USE_FUSED_ATTN and blk.dim in RING_ATTN_FUSED_PROJ and blk.window_size in wins
             and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % blk.window_size == 0):
-        aimg = _ptr(keep(wattn_ring_image(blk.attn.qkv.weight, blk.attn.proj.weight, blk.num_heads,
-                                          RING_ATTN_FUSED_PROJ[blk.dim])))
+        aimg = _ptr(keep.image(wattn_ring_image, (blk.attn.qkv.weight, blk.attn.proj.weight), blk.num_heads,
+                               RING_ATTN_FUSED_PROJ[blk.dim]))
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
-        img = _ptr(keep(mlp_image(blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
+        img = _ptr(keep.image(mlp_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
     elif USE_FUSED_MLP and blk.dim in STREAM_MLP_HC:
-        img = _ptr(keep(mlp_stream_image(blk.mlp.fc1.weight, blk.mlp.fc2.weight, STREAM_MLP_HC[blk.dim])))
+        img = _ptr(keep.image(mlp_stream_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight), STREAM_MLP_HC[blk.dim]))
     return L.SwgBlock(blk.dim, blk.input_resolution[0], blk.window_size, blk.shift_size, blk.num_heads, cond_off,
                       keep.ln(blk.norm1), keep.ln(blk.norm2),
                       keep.lin(blk.attn.qkv.weight, blk.attn.qkv.bias), keep.lin(blk.attn.proj.weight, blk.attn.proj.bias),
@@ -248,6 +317,7 @@ def nodeadj_desc(keep: Keep, model, p: int) -> L.SwgNodeAdj:
     bb = torch.zeros((p * p, Cp), dtype=torch.float32, device=weff.device)
     bb[:, :C0] = beff.float()
     keep(wb), keep(bb)
+    keep.na_bufs = (wb, bb)
     ro = L.SwgLin(_ptr(wb), _ptr(bb), p * p * Cp, C0, Cp)
     am, nm = model.readout_adj_mlp, model.readout_node_mlp
     return L.SwgNodeAdj(model.out_chans_adj, model.out_chans_node, ro,
@@ -259,7 +329,8 @@ class NetCache:
     """Descriptor + derived weights of one SwinGNN module on one device."""
 
     def __init__(self, model):
-        keep = self.keep = Keep()
+        keep = self.keep = Keep(registry=[])
+        self.generation = 0
         dev = model.norm.weight.device
         if dev.type != "cuda":
             raise RuntimeError("swingnn_amd runs on an MI355X only (module parameters are on %s); there is no "
@@ -297,11 +368,15 @@ class NetCache:
         if hasattr(model, "readout_adj_mlp"):  # NodeAdjSwinGNN: C0 -> C0 read-out + two MLP heads
             ro_w, ro_b = None, 0.0
             self.nodeadj = keep(nodeadj_desc(keep, model, p))
+            self._na_wb, self._na_bb = keep.na_bufs
         else:
             ro_w, ro_b = collapse_read_out(model.read_out, p)
             keep(ro_w)
         pe = model.patch_embed
-        pe_w = keep(_f32(pe.proj.weight).reshape(C0, -1).contiguous())
+        pe_w = keep(_f32(pe.proj.weight).reshape(C0, -1).clone())
+        self._aff_mods = [model.patch_embed.affine] + [blk.affine for layer in list(model.down_layers) + list(model.up_layers)
+                                                      for blk in layer.blocks]
+        self._aw, self._ab, self._pe_w, self._ro_w, self._p = aw, ab, pe_w, ro_w, p
         self.net = L.SwgNet(
             pe.img_size[0], p, pe.in_chans, C0, 2 * model.num_layers, int(model.self_condition), off, 0,
             _ptr(freqs), keep.f32(model.map_layer0.weight), keep.f32(model.map_layer0.bias),
@@ -310,6 +385,27 @@ class NetCache:
             C.cast(layers, C.POINTER(L.SwgLayer)), keep.ln(model.norm), _ptr(ro_w), ro_b)
         self.layers = layers
         self._ws_bytes = {}
+        self.table = RefreshTable(keep.registry, dev)
+
+    def refresh(self, model):
+        """Rewrite every derived operand in place from the current parameters (after an optimizer step): one
+        swg_refresh_derived launch for the bf16 operands, a few torch copies for the small fp32 ones.  Pointers and
+        descriptors stay valid."""
+        self.table.run()
+        with torch.no_grad():
+            torch.cat([m.weight for m in self._aff_mods], dim=0, out=self._aw)
+            torch.cat([m.bias for m in self._aff_mods], dim=0, out=self._ab)
+            self._pe_w.copy_(model.patch_embed.proj.weight.reshape(self._pe_w.shape))
+            if self.nodeadj is not None:
+                weff, beff = collapse_read_out_nodeadj(model.read_out, self._p)
+                C0 = model.embed_dim
+                self._na_wb[:, :C0, :C0] = weff
+                self._na_bb[:, :C0] = beff.float()
+            else:
+                ro_w, ro_b = collapse_read_out(model.read_out, self._p)
+                self._ro_w.copy_(ro_w)
+                self.net.ro_b = ro_b
+        self.generation += 1
 
     def ws_bytes(self, B: int) -> int:
         n = self._ws_bytes.get(B)
@@ -329,13 +425,19 @@ class NetCache:
 
 def params_key(model):
     ps = list(model.parameters())
-    return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), str(ps[0].device))
+    return (tuple(p._version for p in ps), ps[0].data_ptr(), ps[-1].data_ptr(), len(ps), str(ps[0].device))
 
 
 def get_cache(model) -> NetCache:
+    """Derived operands of `model`: built once per parameter storage; when only the VALUES changed (version counters
+    moved: optimizer step, load_state_dict) they are refreshed in place."""
     key = params_key(model)
-    if getattr(model, "_swg_key", None) != key:
-        model._swg_cache = NetCache(model)
+    old = getattr(model, "_swg_key", None)
+    if old != key:
+        if old is not None and old[1:] == key[1:] and getattr(model, "_swg_cache", None) is not None:
+            model._swg_cache.refresh(model)
+        else:
+            model._swg_cache = NetCache(model)
         model._swg_key = key
     return model._swg_cache
 

@@ -45,12 +45,16 @@ class TrainCache:
 
     def __init__(self, model, cache: E.NetCache):
         self.model = model
+        self.generation = cache.generation
         self.wt = {}
+        registry = []
         for name, p in model.named_parameters():
             if p.dim() == 2 and name.endswith("weight") and ".affine." not in name and "map_layer" not in name:
                 self.wt[name] = _wt(p)
+                registry.append(("padT", (p,), self.wt[name], None))
         pe = model.patch_embed
         self.pe_wb = _padded_bf16(pe.proj.weight.detach().reshape(model.embed_dim, -1))
+        registry.append(("pad", (pe.proj.weight,), self.pe_wb, None))
         self.nodeadj = cache.nodeadj is not None
         if self.nodeadj:  # collapsed read-out map [p*p*Cp, Cp] transposed: operand of dxn = drep Wro
             p_, C0 = pe.patch_size[0], model.embed_dim
@@ -63,6 +67,22 @@ class TrainCache:
             ro_w, _ = E.collapse_read_out(model.read_out, pe.patch_size[0])
             self.ro_wb = _padded_bf16(ro_w)
         self._ws = {}
+        self.table = E.RefreshTable(registry, pe.proj.weight.device)
+
+    def refresh(self, cache):
+        """Rewrite the transposed / padded operands in place after the parameters changed."""
+        model = self.model
+        self.table.run()
+        with torch.no_grad():
+            p_ = model.patch_embed.patch_size[0]
+            if self.nodeadj:
+                C0 = model.embed_dim
+                weff, _ = E.collapse_read_out_nodeadj(model.read_out, p_)
+                self.ro_wt.view(C0, p_ * p_, -1)[:, :, :C0] = weff.permute(2, 0, 1)
+            else:
+                ro_w, _ = E.collapse_read_out(model.read_out, p_)
+                self.ro_wb[:, :ro_w.shape[1]] = ro_w
+        self.generation = cache.generation
 
     def ws_bytes(self, cache, B):
         n = self._ws.get(B)
@@ -81,6 +101,8 @@ def get_train_cache(model, cache):
     if getattr(model, "_swg_train_key", None) is not cache:
         model._swg_train_cache = TrainCache(model, cache)
         model._swg_train_key = cache
+    elif model._swg_train_cache.generation != cache.generation:
+        model._swg_train_cache.refresh(cache)
     return model._swg_train_cache
 
 

@@ -121,3 +121,42 @@ def test_train_steps_reduce_loss(golden_meta, monkeypatch):
             losses.append(float(loss.detach()))
     assert all(np.isfinite(losses)), losses
     assert losses[-1] < losses[0], losses
+
+
+@pytest.mark.parametrize("kind", ["swingnn", "nodeadj"])
+def test_derived_operand_refresh_equals_rebuild(golden_meta, golden_nodeadj, kind):
+    """After the parameters change in place (optimizer step), engine.get_cache refreshes every derived operand with
+    one swg_refresh_derived launch: each refreshed buffer must equal the buffer of a cache built from scratch."""
+    import swingnn_amd as S
+    from swingnn_amd import engine as E, train as T
+    if kind == "swingnn":
+        from tests.test_gpu_parity import build_precond
+        model = build_precond(S, "grid192", golden_meta, "init").model
+    else:
+        from tests.test_gpu_nodeadj import build
+        model = build(S, "qm9_onehot96", golden_nodeadj[1], "init", 3).model
+    cache = E.get_cache(model)
+    tcache = T.get_train_cache(model, cache)
+    with torch.no_grad():
+        for i, p in enumerate(model.parameters()):
+            p.add_(0.01 * torch.randn_like(p))
+    again = E.get_cache(model)
+    assert again is cache and cache.generation == 1            # refreshed in place, descriptors untouched
+    tagain = T.get_train_cache(model, cache)
+    assert tagain is tcache and tcache.generation == 1
+    fresh = E.NetCache(model)
+    tfresh = T.TrainCache(model, fresh)
+    assert len(cache.keep.registry) == len(fresh.keep.registry) > 10
+    for (m0, _, d0, _), (m1, _, d1, _) in zip(cache.keep.registry, fresh.keep.registry):
+        assert m0 == m1 and torch.equal(d0, d1), m0
+    for name in ("_aw", "_ab", "_pe_w"):
+        assert torch.equal(getattr(cache, name), getattr(fresh, name)), name
+    if kind == "swingnn":
+        assert torch.allclose(cache._ro_w, fresh._ro_w, rtol=1e-6, atol=1e-9) and abs(cache.net.ro_b - fresh.net.ro_b) < 1e-6
+        assert torch.equal(tcache.ro_wb, tfresh.ro_wb)
+    else:
+        assert torch.equal(cache._na_wb, fresh._na_wb) and torch.equal(cache._na_bb, fresh._na_bb)
+        assert torch.equal(tcache.ro_wt, tfresh.ro_wt)
+    for k in tcache.wt:
+        assert torch.equal(tcache.wt[k], tfresh.wt[k]), k
+    assert torch.equal(tcache.pe_wb, tfresh.pe_wb)
