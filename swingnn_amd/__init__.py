@@ -11,7 +11,8 @@ from .precond import Precond, NodeAdjPrecond
 from .edm_sampler import EDMSampler, GeneralSampler, NodeAdjEDMSampler
 from .objective import EDMObjectiveGenerator, RainbowLoss, NodeAdjEDMObjectiveGenerator, NodeAdjRainbowLoss
 from .optim import FusedAdamEMA
+from .io import load_model, adjs_to_dataset_tensors, quantise_samples
 
 __all__ = ["SwinGNN", "SwinTransformerBlock", "WindowAttention", "PatchMerging", "PatchBreakup", "PatchEmbed",
            "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler", "EDMObjectiveGenerator", "RainbowLoss",
-           "FusedAdamEMA", "NodeAdjSwinGNN", "NodeAdjPrecond", "NodeAdjEDMSampler", "NodeAdjEDMObjectiveGenerator", "NodeAdjRainbowLoss"]
+           "FusedAdamEMA", "NodeAdjSwinGNN", "NodeAdjPrecond", "NodeAdjEDMSampler", "NodeAdjEDMObjectiveGenerator", "NodeAdjRainbowLoss", "load_model", "adjs_to_dataset_tensors", "quantise_samples"]

@@ -1,0 +1,68 @@
+"""Host-side data formats either side of the hot path: checkpoint loading, dataset tensorisation and
+the post-sampling quantisation, with the reference's semantics.  Pure host code (numpy / torch CPU ops on data that the
+reference also handles on the host); nothing here is on the timed path.
+"""
+import numpy as np
+import torch
+
+
+def load_model(ckp_data, model, weight_keyword):
+    """utils/sampling_utils.py:87-113: strict load of ``ckp_data[weight_keyword]`` into ``model``; a ``module.`` prefix
+    on either side (DDP / DataParallel checkpoints, runner/trainer/trainer_utils.py:164-181) is reconciled by sorted
+    key order exactly as the reference does."""
+    assert weight_keyword in ckp_data
+    cur_keys = sorted(list(model.state_dict().keys()))
+    ckp_keys = sorted(list(ckp_data[weight_keyword].keys()))
+    if set(cur_keys) == set(cur_keys) & set(ckp_keys):
+        model.load_state_dict(ckp_data[weight_keyword], strict=True)
+        return model
+    to_load = {}
+    for cur_key, ckp_key in zip(cur_keys, ckp_keys):
+        if cur_key == ckp_key:
+            pass
+        elif cur_key.startswith('module.') and not ckp_key.startswith('module.'):
+            assert cur_key == 'module.' + ckp_key
+        elif ckp_key.startswith('module.') and not cur_key.startswith('module.'):
+            assert 'module.' + cur_key == ckp_key
+        else:
+            raise NotImplementedError
+        to_load[cur_key] = ckp_data[weight_keyword][ckp_key]
+    assert set(cur_keys) == set(to_load.keys())
+    model.load_state_dict(to_load, strict=True)
+    return model
+
+
+def pad_adjs(adj, node_number):
+    """utils/graph_utils.py:97-110."""
+    a = np.asarray(adj)
+    n = a.shape[-1]
+    if n == node_number:
+        return a
+    if n > node_number:
+        raise ValueError(f'ori_len {n} > node_number {node_number}')
+    out = np.zeros((node_number, node_number), dtype=a.dtype)
+    out[:n, :n] = a
+    return out
+
+
+def adjs_to_dataset_tensors(adjs, max_node_num, ddpm_scale=True):
+    """utils/dataloader.py:219-247 (``_nx_graphs_to_dataset`` after ``nx.to_numpy_matrix``): list of 0/1 adjacency
+    matrices -> (adjs [B,N,N] float32, dummy node features [B,N,1], node_flags [B,N]).  ``node_flags`` marks rows
+    with at least one edge BEFORE the rescale (:238, isolated nodes count as padding); with ``ddpm_scale`` the entries
+    of valid rows / columns go {0,1} -> {-1,+1} and padding stays 0 (utils/attribute_code.py, 2 attribute types)."""
+    a = torch.tensor(np.asarray([pad_adjs(x, max_node_num) for x in adjs]), dtype=torch.float32)
+    node_feat = torch.zeros(a.shape[:2], dtype=torch.float32).unsqueeze(-1)
+    flags = a.sum(-1).gt(1e-5).to(torch.float32)
+    if ddpm_scale:
+        keep = flags[:, :, None] * flags[:, None, :]
+        a = (a * 2.0 - 1.0) * keep
+    return a, node_feat, flags
+
+
+def quantise_samples(final_samples, node_flags):
+    """Post-sampling quantisation of runner/sampler/sampler.py:131-135: clamp to [-1, 1], 2-type ddpm -> int
+    (``x > 0``), masked by the node flags (utils/attribute_code.py:133-159)."""
+    x = final_samples.clamp(min=-1.0, max=1.0)
+    keep = node_flags.to(torch.bool)
+    keep = keep[..., :, None] & keep[..., None, :]
+    return ((x > 0) & keep).to(final_samples.dtype)

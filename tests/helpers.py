@@ -170,3 +170,14 @@ def mmd_graph_sets(golden):
         sets[f"ref_sampler/{case}"] = (synthetic_graphs("testset", 6, pred.shape[-1], 4, 18, 0.3, 91), pred)
     sets["synthetic"] = (synthetic_graphs("setA", 8, 20, 12, 20, 0.35, 92), synthetic_graphs("setB", 7, 20, 10, 20, 0.2, 93))
     return sets
+
+
+def synthetic_graph_list():
+    """Variable-size 0/1 adjacency matrices (numpy), some with isolated nodes, for the dataset-tensorisation golden."""
+    out = []
+    for k, n in enumerate((5, 12, 20, 9, 16)):
+        a = synthetic_graphs(f"ds{k}", 1, n, n, n, 0.25, 100 + k)[0]
+        if k == 1:
+            a[3, :] = 0; a[:, 3] = 0     # an isolated node inside the graph: flagged as padding (dataloader.py:238)
+        out.append(a.astype(np.float64))
+    return out
