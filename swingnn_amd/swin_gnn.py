@@ -264,8 +264,22 @@ class PatchEmbed(nn.Module):
         return out
 
 
+def _deepcopy_without_caches(self, memo):
+    """copy.deepcopy of a denoiser (ema_pytorch.EMA deep-copies the model, utils/learning_utils.py:268) must not drag
+    the derived-operand caches along (device descriptors, ctypes pointers): the copy builds its own on first use."""
+    import copy
+    new = self.__class__.__new__(self.__class__)
+    memo[id(self)] = new
+    for k, v in self.__dict__.items():
+        if not k.startswith("_swg_"):
+            new.__dict__[k] = copy.deepcopy(v, memo)
+    return new
+
+
 class SwinGNN(nn.Module):
     """Swin-UNet denoiser on N x N adjacency matrices (reference :587-779), executed by HIP kernels."""
+
+    __deepcopy__ = _deepcopy_without_caches
 
     def __init__(self, img_size=224, patch_size=4, in_chans=3, embed_dim=96, depths=[2, 2, 6, 2],
                  num_heads=[3, 6, 12, 24], window_size=7, mlp_ratio=4., qkv_bias=True, qk_scale=None,
@@ -411,6 +425,7 @@ class NodeAdjSwinGNN(nn.Module):
         self.apply(self._init_weights)
 
     _init_weights = SwinGNN._init_weights
+    __deepcopy__ = _deepcopy_without_caches
 
     @torch.jit.ignore
     def no_weight_decay(self):

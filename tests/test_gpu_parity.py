@@ -335,6 +335,30 @@ def test_edm_sampler(S, golden, golden_meta, name):
         assert np.allclose(mine, mmd_ref, rtol=0, atol=(1e-9 if flips == 0 else 2e-2)), (mine, mmd_ref)
 
 
+def test_deepcopy_after_forward(S, golden_meta):
+    """ema_pytorch.EMA deep-copies the model (utils/learning_utils.py:268): a copy taken after a forward (derived
+    caches exist) must work, own its caches and follow its own parameters."""
+    import copy
+    nc = NET_CASES["ego60"]
+    pre = build_precond(S, "ego60", golden_meta, "init")
+    flags, x, sig, _ = H.net_inputs(nc, 1)
+    np.random.seed(0)
+    a = pre(x.to(DEV), flags.to(DEV), sig.to(DEV))
+    twin = copy.deepcopy(pre)
+    assert getattr(twin.model, "_swg_cache", None) is None
+    np.random.seed(0)
+    b = twin(x.to(DEV), flags.to(DEV), sig.to(DEV))
+    assert torch.equal(a, b)
+    with torch.no_grad():
+        for p in twin.parameters():
+            p.mul_(1.05)
+    np.random.seed(0)
+    c = twin(x.to(DEV), flags.to(DEV), sig.to(DEV))
+    np.random.seed(0)
+    d = pre(x.to(DEV), flags.to(DEV), sig.to(DEV))
+    assert torch.equal(a, d) and not torch.equal(b, c)
+
+
 def test_pass_reuse_is_bit_identical(S, golden_meta):
     """EDMSampler.reuse_passes (opt-in): both model calls of a Heun step evaluate the same (x_hat, sigma_hat), so the
     sampler may reuse P0 / P1 inside a step.  Same seeds -> the samples must be bit-identical to the default run, with
