@@ -110,7 +110,9 @@ int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void*
   if (blk->mlp_img && mlp_fused_supported(C))
     return launch_mlp_fused(C, T, x_in, x_out, (const bf16*)blk->mlp_img, blk->fc1.b, blk->fc2.b, blk->ln2.g,
                             blk->ln2.b, s);
-  if (blk->mlp_img && mlp_stream_supported(C))
+  // the streamed kernel pays a fixed weight-stream latency per workgroup (~90 us at C = 384, ~35 us at C = 192): below
+  // these token counts the three-kernel GEMM path is faster (measured: community-small, 4 / 16 tokens per graph)
+  if (blk->mlp_img && mlp_stream_supported(C) && T >= (C == 384 ? 16384 : 8192))
     return launch_mlp_stream(C, T, x_in, x_out, (const bf16*)blk->mlp_img, blk->fc1.b, blk->fc2.b, blk->ln2.g,
                              blk->ln2.b, s);
   Carver cv(ws, ws_bytes);
