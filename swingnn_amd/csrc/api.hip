@@ -207,7 +207,7 @@ int plan_net(const swg_net* net, int B, NetPlan* pl) {
   if (net->N <= 0 || net->p <= 0 || net->N % net->p || net->n_layers <= 0 || net->n_layers % 2) return SWG_E_SHAPE;
   const int hp = net->N / net->p;
   size_t scratch = ws_embed(B, net->C0);
-  scratch = max(scratch, ws_readout(B, net->N));
+  scratch = smax(scratch, ws_readout(B, net->N));
   size_t maxTC = (size_t)B * hp * hp * net->C0;
   size_t skips = 0;
   const int S = net->n_layers / 2;
@@ -215,18 +215,18 @@ int plan_net(const swg_net* net, int B, NetPlan* pl) {
     const swg_layer& ly = net->layers[li];
     if (ly.up) {
       const int T = B * ly.up->res * ly.up->res;
-      scratch = max(scratch, ws_expand(T, ly.up->Cin));
-      maxTC = max(maxTC, (size_t)4 * T * (ly.up->Cin / 4));
+      scratch = smax(scratch, ws_expand(T, ly.up->Cin));
+      maxTC = smax(maxTC, (size_t)4 * T * (ly.up->Cin / 4));
     }
     for (int j = 0; j < ly.n_blocks; ++j) {
       const swg_block& b = ly.blocks[j];
       const int T = B * b.res * b.res;
-      scratch = max(scratch, max(ws_wattn(T, b.C), ws_mlp(T, b.C)));
-      maxTC = max(maxTC, (size_t)T * b.C);
+      scratch = smax(scratch, smax(ws_wattn(T, b.C), ws_mlp(T, b.C)));
+      maxTC = smax(maxTC, (size_t)T * b.C);
     }
     if (ly.down) {
       const int T = B * ly.down->res * ly.down->res;
-      scratch = max(scratch, ws_merge(T, ly.down->C));
+      scratch = smax(scratch, ws_merge(T, ly.down->C));
       if (li < S) skips += align256((size_t)(T / 4) * 2 * ly.down->C * 4);
     }
   }
@@ -251,7 +251,7 @@ int carve_trunk(const swg_net* net, int B, int labels_uniform, void* ws, size_t 
   NetPlan pl;
   int r = plan_net(net, B, &pl);
   if (r) return r;
-  if (ws_bytes < pl.persistent + max(pl.scratch, extra_scratch)) return SWG_E_WORKSPACE;
+  if (ws_bytes < pl.persistent + smax(pl.scratch, extra_scratch)) return SWG_E_WORKSPACE;
   const int S = net->n_layers / 2;
   if (S > 8) return SWG_E_UNSUPPORTED;
   Carver cv(ws, ws_bytes);
@@ -446,7 +446,7 @@ int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float
 size_t swg_nodeadj_workspace_bytes(const swg_net* net, const swg_nodeadj* na, int32_t B) {
   NetPlan pl;
   if (B <= 0 || !na || plan_net(net, B, &pl)) return 0;
-  return pl.persistent + max(pl.scratch, ws_na_tail(net, na, B)) + 4096;
+  return pl.persistent + smax(pl.scratch, ws_na_tail(net, na, B)) + 4096;
 }
 
 int swg_nodeadj_forward(const swg_net* net, const swg_nodeadj* na, int32_t B, int32_t mode, const float* adj,

@@ -396,30 +396,30 @@ size_t swg_train_workspace_bytes(const swg_net* net, int32_t B) {
   {
     Carver cv;
     embed_bwd_impl(net, nullptr, B, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr, nullptr, 0, cv, nullptr);
-    need = max(need, cv.used);
+    need = smax(need, cv.used);
   }
   {
     Carver cv;
     readout_bwd_impl(net, nullptr, B, nullptr, nullptr, nullptr, nullptr, nullptr, cv, nullptr);
-    need = max(need, cv.used);
+    need = smax(need, cv.used);
   }
   for (int li = 0; li < net->n_layers; ++li) {
     const swg_layer& ly = net->layers[li];
     if (ly.up) {
       Carver cv;
       expand_bwd_impl(ly.up, nullptr, B, nullptr, nullptr, nullptr, nullptr, nullptr, cv, nullptr);
-      need = max(need, cv.used);
+      need = smax(need, cv.used);
     }
     for (int j = 0; j < ly.n_blocks; ++j) {
       Carver c1, c2;
       wattn_bwd_impl(&ly.blocks[j], nullptr, B, nullptr, nullptr, 0, nullptr, nullptr, nullptr, 0, c1, nullptr);
       mlp_bwd_impl(&ly.blocks[j], nullptr, B, nullptr, nullptr, nullptr, c2, nullptr);
-      need = max(need, max(c1.used, c2.used));
+      need = smax(need, smax(c1.used, c2.used));
     }
     if (ly.down) {
       Carver cv;
       merge_bwd_impl(ly.down, nullptr, B, nullptr, nullptr, nullptr, cv, nullptr);
-      need = max(need, cv.used);
+      need = smax(need, cv.used);
     }
   }
   return need + 4096;
@@ -494,12 +494,12 @@ size_t swg_nodeadj_train_workspace_bytes(const swg_net* net, const swg_nodeadj* 
     Carver cv;
     na_embed_bwd_impl(net, na, nullptr, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, 0, nullptr, 0, nullptr,
                       nullptr, 0, cv, nullptr);
-    need = max(need, cv.used + 4096);
+    need = smax(need, cv.used + 4096);
   }
   {
     Carver cv;
     na_readout_bwd_impl(net, na, nullptr, B, nullptr, nullptr, nullptr, nullptr, nullptr, nullptr, cv, nullptr);
-    need = max(need, cv.used + 4096);
+    need = smax(need, cv.used + 4096);
   }
   return need;
 }

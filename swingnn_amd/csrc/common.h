@@ -20,6 +20,9 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
+// byte counts go through this, never through an unqualified max(): in a .hip translation unit max(size_t, size_t) can
+// bind to the int overload and silently drops every term above 2^31 (a workspace plan that shrinks as the batch grows)
+static inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
 
 // x * sigmoid(x) with the hardware reciprocal (1 ulp): a true IEEE division costs ~10 VALU instructions
 __device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }

@@ -216,3 +216,33 @@ def test_nodeadj_collapsed_read_out(S, golden_nodeadj):
     mine = torch.einsum("koi,biyx->bykxo", w, x) + b                   # [B, Y, k = i*p+j, X, Cout]
     mine = mine.reshape(2, 3, p, p, 3, C0).permute(0, 5, 1, 2, 4, 3).reshape(2, C0, 3 * p, 3 * p)
     assert torch.allclose(mine, y, atol=1e-9)
+
+
+def test_workspace_plans_scale_with_batch(S):
+    """The host-only planning entry points (swg_workspace_bytes / swg_train_workspace_bytes / the NodeAdj variants) must
+    grow monotonically and ~linearly with the batch, also past 2 GiB per term (a max() over byte counts that bound to the
+    int overload once dropped every term above 2^31: training grid graphs at B >= 56 failed with SWG_E_WORKSPACE)."""
+    from swingnn_amd import engine as E, _lib as L
+    from tests.golden.cases import NODEADJ_CASES
+    E.HOST_DESCRIPTORS_FOR_TESTS = True
+    try:
+        grid = dict(img_size=384, patch_size=4, in_chans=1, embed_dim=96, depths=[1, 1, 3, 1], num_heads=[3, 6, 12, 24],
+                    window_size=6, self_condition=True)
+        nets = [(build(S, grid).model, (8, 48, 64, 112, 256)),
+                (build_nodeadj(S, NODEADJ_CASES["qm9_onehot96"]["cfg"]).model, (64, 1280, 10240, 40960))]
+        for model, batches in nets:
+            cache = E.NetCache(model)
+            fwd = [cache.ws_bytes(B) for B in batches]
+            if cache.nodeadj is not None:
+                trn = [int(L.lib.swg_nodeadj_train_workspace_bytes(C.byref(cache.net), C.byref(cache.nodeadj), B)) for B in batches]
+            else:
+                trn = [int(L.lib.swg_train_workspace_bytes(C.byref(cache.net), B)) for B in batches]
+            for sizes in (fwd, trn):
+                assert all(s > 0 for s in sizes)
+                for (b0, s0), (b1, s1) in zip(zip(batches, sizes), zip(batches[1:], sizes[1:])):
+                    assert s1 > s0, (b0, s0, b1, s1)
+                    if s0 > (1 << 30):  # past the fixed split-K buffers the plan is linear in the batch
+                        assert abs(s1 / s0 - b1 / b0) < 0.1 * b1 / b0, (b0, s0, b1, s1)
+            assert trn[-1] > (1 << 32)
+    finally:
+        E.HOST_DESCRIPTORS_FOR_TESTS = False
