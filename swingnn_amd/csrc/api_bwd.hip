@@ -56,6 +56,12 @@ int wgrad(const float* dy_f32, const bf16* dy_b, int ldy, int N, const bf16* xb,
   return launch_gemm_splitk(w.tA, Tp, w.tB, Tp, N, K, Tp, dw, w.partial, w.partial_floats, s);
 }
 
+// dW[N,K] += dY^T X on the token-major operands themselves (k_gemm_tn): dY bf16 [rows, ldy], X bf16 [rows, ldx]
+int wgrad_tn(const bf16* dy_b, int ldy, int N, const bf16* xb, int ldx, int K, int rows, float* dw, const WgradScratch& w,
+             hipStream_t s) {
+  return launch_gemm_tn_splitk(dy_b, ldy, xb, ldx, rows, N, K, dw, w.partial, w.partial_floats, s);
+}
+
 int check_lin_train(const swg_lin_train& t, bool bias) {
   if (!t.wt || !t.dw || (bias && !t.db)) return SWG_E_NULL;
   return 0;
@@ -90,7 +96,7 @@ int wattn_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const
   GemmEpi e1 = {};
   e1.out_bf16 = dO; e1.ldo = Cp; e1.n_store = Cp;
   if ((r = launch_gemm(dyb, Cp, (const bf16*)tr->proj.wt, T, C, Cp, e1, s))) return r;
-  if ((r = wgrad(dy, nullptr, C, C, o, Cp, C, T, tr->proj.dw, w, s))) return r;
+  if ((r = wgrad_tn(dyb, Cp, C, o, Cp, C, T, tr->proj.dw, w, s))) return r;
   if ((r = launch_colsum_f32(dy, T, C, C, tr->proj.db, s))) return r;
   // ---- attention core ----
   if ((r = launch_wattn_bwd(qkv, ldq, dO, Cp, B, blk->res, blk->win, blk->shift, blk->heads, C, blk->rpb, dqkv, Q3p,
@@ -100,7 +106,7 @@ int wattn_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const
   GemmEpi e2 = {};
   e2.out_f32 = dxn; e2.ldo = C;
   if ((r = launch_gemm(dqkv, Q3p, (const bf16*)tr->qkv.wt, T, C, Q3p, e2, s))) return r;
-  if ((r = wgrad(nullptr, dqkv, Q3p, 3 * C, xn, Cp, C, T, tr->qkv.dw, w, s))) return r;
+  if ((r = wgrad_tn(dqkv, Q3p, 3 * C, xn, Cp, C, T, tr->qkv.dw, w, s))) return r;
   if ((r = launch_colsum_bf16(dqkv, T, 3 * C, Q3p, tr->qkv.db, s))) return r;
   // ---- LN1 + shortcut (:241-244, :272): dxc = dy + d LN1 ----
   if ((r = launch_ln_bwd(x1, dxn, blk->ln1.g, dy, T, C, dxc, tr->ln1.dg, tr->ln1.db, s))) return r;
@@ -134,14 +140,14 @@ int mlp_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const f
   GemmEpi e1 = {};
   e1.out_bf16 = da; e1.ldo = Hp; e1.n_store = Hp;
   if ((r = launch_gemm(dyb, Cp, (const bf16*)tr->fc2.wt, T, H, Cp, e1, s))) return r;
-  if ((r = wgrad(dy, nullptr, C, C, a, Hp, H, T, tr->fc2.dw, w, s))) return r;
+  if ((r = wgrad_tn(dyb, Cp, C, a, Hp, H, T, tr->fc2.dw, w, s))) return r;
   if ((r = launch_colsum_f32(dy, T, C, C, tr->fc2.db, s))) return r;
   // ---- GELU, fc1 ----
   if ((r = launch_gelu_bwd(h, da, da, (size_t)T * Hp, s))) return r;
   GemmEpi e2 = {};
   e2.out_f32 = dxn; e2.ldo = C;
   if ((r = launch_gemm(da, Hp, (const bf16*)tr->fc1.wt, T, C, Hp, e2, s))) return r;
-  if ((r = wgrad(nullptr, da, Hp, H, xn, Cp, C, T, tr->fc1.dw, w, s))) return r;
+  if ((r = wgrad_tn(da, Hp, H, xn, Cp, C, T, tr->fc1.dw, w, s))) return r;
   if ((r = launch_colsum_bf16(da, T, H, Hp, tr->fc1.db, s))) return r;
   // ---- LN2 + residual ----
   return launch_ln_bwd(x_in, dxn, blk->ln2.g, dy, T, C, dx, tr->ln2.dg, tr->ln2.db, s);
@@ -166,7 +172,7 @@ int merge_bwd_impl(const swg_merge* m, const swg_merge_train* tr, int B, const f
   GemmEpi e = {};
   e.out_f32 = dxn; e.ldo = K4;
   if ((r = launch_gemm(dyb, N2p, (const bf16*)tr->red.wt, T4, K4, N2p, e, s))) return r;
-  if ((r = wgrad(dy, nullptr, N2, N2, xn, K4p, K4, T4, tr->red.dw, w, s))) return r;
+  if ((r = wgrad_tn(dyb, N2p, N2, xn, K4p, K4, T4, tr->red.dw, w, s))) return r;
   if ((r = launch_ln_bwd(xg, dxn, m->ln.g, nullptr, T4, K4, dxn, tr->ln.dg, tr->ln.db, s))) return r;
   return launch_perm22(dxn, dx, B, m->res, C, 1, s);
 }
@@ -202,7 +208,7 @@ int expand_bwd_impl(const swg_breakup* u, const swg_breakup_train* tr, int B, co
   GemmEpi e1 = {};
   e1.out_f32 = dzn; e1.ldo = Co;
   if ((r = launch_gemm(dyb, Cop, (const bf16*)tr->post.wt, T4, Co, Cop, e1, s))) return r;
-  if ((r = wgrad(dy, nullptr, Co, Co, zn, Cop, Co, T4, tr->post.dw, w, s))) return r;
+  if ((r = wgrad_tn(dyb, Cop, Co, zn, Cop, Co, T4, tr->post.dw, w, s))) return r;
   if ((r = launch_ln_bwd(z, dzn, u->post_ln.g, nullptr, T4, Co, dzn, tr->post_ln.dg, tr->post_ln.db, s))) return r;
   // ---- scatter, norm, pre_linear ----
   if ((r = launch_perm22(dzn, dyn, B, 2 * u->res, Co, 0, s))) return r;
@@ -214,7 +220,7 @@ int expand_bwd_impl(const swg_breakup* u, const swg_breakup_train* tr, int B, co
   if ((r = launch_gemm(dyb2, Kp, wt, T, Cin / 2, Kp, e2, s))) return r;
   e2.out_f32 = dskip;
   if ((r = launch_gemm(dyb2, Kp, wt + (size_t)(Cin / 2) * Kp, T, Cin / 2, Kp, e2, s))) return r;
-  return wgrad(dyn, nullptr, Cin, Cin, cat, Kp, Cin, T, tr->pre.dw, w, s);
+  return wgrad_tn(dyb2, Kp, Cin, cat, Kp, Cin, T, tr->pre.dw, w, s);
 }
 
 int embed_bwd_impl(const swg_net* net, const swg_ends_train* tr, int B, const float* x, const float* sc, const float* c_in,
@@ -267,7 +273,7 @@ int readout_bwd_impl(const swg_net* net, const swg_ends_train* tr, int B, const 
   if ((r = launch_gemm(dpix, Kp, (const bf16*)tr->ro_wb, T, C0, Kp, e, s))) return r;
   hipError_t he = hipMemsetAsync(tmp, 0, (size_t)C0 * Kp * sizeof(float), s);
   if (he != hipSuccess) return (int)he;
-  if ((r = wgrad(nullptr, tn, Cp, C0, dpix, Kp, Kp, T, tmp, w, s))) return r;
+  if ((r = wgrad_tn(tn, Cp, C0, dpix, Kp, Kp, T, tmp, w, s))) return r;
   if ((r = launch_add_slice(tmp, C0, pp, Kp, tr->dro_w, s))) return r;
   if ((r = launch_colsum_bf16(dpix, T, Kp, Kp, tr->dro_b, s))) return r;
   return launch_ln_bwd(tok, dtn, net->norm.g, nullptr, T, C0, dtok, tr->norm.dg, tr->norm.db, s);
@@ -323,7 +329,7 @@ int na_head_bwd(const swg_lin& fc1, const swg_lin_train& t1, const float* w2, fl
   e2.out_f32 = din; e2.ldo = C0;
   if (accumulate) { e2.residual = din; e2.ldr = C0; }
   if ((r = launch_gemm(act, Cp, (const bf16*)t1.wt, rows, C0, Cp, e2, s))) return r;
-  if ((r = wgrad(nullptr, act, Cp, C0, in, Cp, C0, rows, t1.dw, w, s))) return r;
+  if ((r = wgrad_tn(act, Cp, C0, in, Cp, C0, rows, t1.dw, w, s))) return r;
   return launch_colsum_bf16(act, rows, C0, Cp, t1.db, s);
 }
 
@@ -381,7 +387,7 @@ int na_readout_bwd_impl(const swg_net* net, const swg_nodeadj* na, const swg_nod
   GemmEpi e2 = {};
   e2.out_f32 = dxn; e2.ldo = C0;
   if ((r = launch_gemm(drepb, pp * Cp, (const bf16*)tr->ro_wt, T, C0, pp * Cp, e2, s))) return r;
-  if ((r = wgrad(nullptr, drepb, pp * Cp, pp * Cp, xn, Cp, C0, T, tr->dro_w, w, s))) return r;
+  if ((r = wgrad_tn(drepb, pp * Cp, pp * Cp, xn, Cp, C0, T, tr->dro_w, w, s))) return r;
   if ((r = launch_colsum_bf16(drepb, T, pp * Cp, pp * Cp, tr->dro_b, s))) return r;
   return launch_ln_bwd(tok, dxn, net->norm.g, nullptr, T, C0, dtok, tr->norm.dg, tr->norm.db, s);
 }

@@ -169,6 +169,118 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
   }
 }
 
+
+// ------------------------------------------------------------------------------------------------------------------
+// Weight-gradient GEMM on TOKEN-MAJOR operands:  out[Mo, No] += sum_t P[t, m] Q[t, n]   (dW = dY^T X)
+// P = dY (bf16 [rows, ldp]) and Q = X (bf16 [rows, ldq]) are read exactly as the forward / backward kernels wrote them:
+// no transposed copies.  A 32-token x 128-feature tile of each operand goes to LDS row-major (coalesced 16-byte
+// loads); the MFMA fragments, which need 8 consecutive TOKENS per lane, are gathered by ds_read_b64_tr_b16 (gfx950
+// transposing LDS read: 4 tokens x 16 features per 16-lane group, delivered feature-per-lane).  Rows are 288 bytes
+// apart (144 elements): the 16 lanes of a group then cover 32 distinct banks; the two groups of a 32-lane half sit 8
+// rows (= 0 mod 64 banks) apart, a 2-way conflict that costs what the NT kernel's ds_read_b128 costs.
+// Split over blockIdx.y along the tokens into fp32 partials like the NT form (k_splitk_reduce folds them).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int TN_BT = 32;    // tokens per k-step
+constexpr int TN_LD = 144;   // LDS row stride in elements
+
+__global__ __launch_bounds__(256) void k_gemm_tn(const bf16* __restrict__ P, int ldp, const bf16* __restrict__ Q, int ldq,
+                                                 int rows, int Mo, int No, float* __restrict__ out, int tiles_n, int kslice,
+                                                 size_t out_slice, int accumulate) {
+  __shared__ __attribute__((aligned(16))) bf16 sP[2][TN_BT * TN_LD];
+  __shared__ __attribute__((aligned(16))) bf16 sQ[2][TN_BT * TN_LD];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * 128, n0 = tn * 128;
+  const int t_begin = blockIdx.y * kslice, t_end = min(rows, t_begin + kslice);
+  float* dst = out + (size_t)blockIdx.y * out_slice;
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // staging: 32 rows x 16 chunks (16 B) per operand = 2 chunks per thread per operand
+  int srow[2], sch[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int id = tid + i * 256;
+    srow[i] = id >> 4;
+    sch[i] = id & 15;
+  }
+  bf16x8 rp[2], rq[2];
+  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
+#define TN_LOAD(T0)                                                                                     \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+    const int t = (T0) + srow[i];                                                                        \
+    const int cm = m0 + sch[i] * 8, cn = n0 + sch[i] * 8;                                                \
+    rp[i] = (t < t_end && cm + 8 <= ldp) ? *reinterpret_cast<const bf16x8*>(P + (size_t)t * ldp + cm) : zero8; \
+    rq[i] = (t < t_end && cn + 8 <= ldq) ? *reinterpret_cast<const bf16x8*>(Q + (size_t)t * ldq + cn) : zero8; \
+  }
+#define TN_STORE(BUF)                                                                                   \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
+    *reinterpret_cast<bf16x8*>(&sP[BUF][srow[i] * TN_LD + sch[i] * 8]) = rp[i];                           \
+    *reinterpret_cast<bf16x8*>(&sQ[BUF][srow[i] * TN_LD + sch[i] * 8]) = rq[i];                           \
+  }
+
+  f32x4 acc[4][4];  // [mt][nt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  // transposed-read addresses: lane 4q+p of group lg supplies row (8 lg + 4 half + q), columns c0 + 4p .. 4p+3
+  const int q4 = l15 >> 2, p4 = l15 & 3;
+  const int roff = (8 * lg + q4) * TN_LD + 4 * p4;  // half 0; half 1 adds 4 rows
+
+  typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+  int buf = 0;
+  if (t_begin < t_end) {
+    TN_LOAD(t_begin);
+    TN_STORE(0);
+  }
+  __syncthreads();
+  for (int t0 = t_begin; t0 < t_end; t0 += TN_BT) {
+    const bool more = t0 + TN_BT < t_end;
+    if (more) { TN_LOAD(t0 + TN_BT); }
+    bf16x8 fa[4], fb[4];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const bf16* pa = &sP[buf][roff + wm * 64 + t * 16];
+      const bf16* pb = &sQ[buf][roff + wn * 64 + t * 16];
+      const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)pa);
+      const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pa + 4 * TN_LD));
+      const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)pb);
+      const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pb + 4 * TN_LD));
+      fa[t] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+      fb[t] = (bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+    if (more) { TN_STORE(buf ^ 1); }
+    __syncthreads();
+    buf ^= 1;
+  }
+#undef TN_LOAD
+#undef TN_STORE
+  // accumulator of tile (mt, nt): row i = 4 lg + r (feature m), column j = l15 (feature n)
+#pragma unroll
+  for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int m = m0 + wm * 64 + mt * 16 + 4 * lg + r;
+      if (m >= Mo) continue;
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt) {
+        const int n = n0 + wn * 64 + nt * 16 + l15;
+        if (n >= No) continue;
+        float* o = dst + (size_t)m * No + n;
+        *o = accumulate ? *o + acc[mt][nt][r] : acc[mt][nt][r];
+      }
+    }
+}
+
 // out[i] += sum_s partial[s][i]
 __global__ __launch_bounds__(256) void k_splitk_reduce(const float* __restrict__ partial, int S, size_t n4, size_t slice,
                                                        float* __restrict__ out) {
@@ -214,6 +326,34 @@ int launch_gemm_splitk(const bf16* A, int lda, const bf16* W, int ldw, int M, in
   if (!partial || partial_floats < slice * S) return SWG_E_WORKSPACE;
   e.out_f32 = partial;
   hipLaunchKernelGGL(k_gemm_nt<32>, dim3(tiles, S), dim3(256), 0, s, A, lda, W, ldw, M, N, Kp, e, tiles_n, kslice, slice);
+  SWG_LAUNCH_CHECK();
+  const size_t n4 = slice / 4;
+  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)min((size_t)1024, (n4 + 255) / 256)), dim3(256), 0, s, partial, S, n4,
+                     slice, out);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int rows, int Mo, int No, float* out,
+                          float* partial, size_t partial_floats, hipStream_t s) {
+  if (rows <= 0 || Mo <= 0 || No <= 0) return 0;
+  if (ldp % 8 || ldq % 8 || No % 4) return SWG_E_SHAPE;
+  if (!P || !Q || !out) return SWG_E_NULL;
+  const int tiles_m = cdiv(Mo, 128), tiles_n = cdiv(No, 128);
+  const int tiles = tiles_m * tiles_n;
+  int S = min(min(cdiv(512, tiles), max(rows / 256, 1)), 64);
+  int kslice = round_up(cdiv(rows, S), TN_BT);
+  S = cdiv(rows, kslice);
+  SwgProfScope ps(KID_GEMM, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
+                                                           8.0 * Mo * (double)No, s);
+  if (S <= 1) {
+    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, kslice, (size_t)0, 1);
+    SWG_LAUNCH_CHECK();
+    return 0;
+  }
+  const size_t slice = (size_t)Mo * No;
+  if (!partial || partial_floats < slice * S) return SWG_E_WORKSPACE;
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n, kslice, slice, 0);
   SWG_LAUNCH_CHECK();
   const size_t n4 = slice / 4;
   hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)min((size_t)1024, (n4 + 255) / 256)), dim3(256), 0, s, partial, S, n4,
