@@ -171,6 +171,134 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
 
 
 // ------------------------------------------------------------------------------------------------------------------
+// Large-shape form: 256 (tokens) x 128 (features) block tile, 4 waves as 2(m) x 2(n), each wave 128 x 64 = 8 x 4 MFMA
+// tiles (128 accumulator VGPRs, two workgroups per CU).  Against the 128 x 128 form this halves the LDS bytes read
+// per MFMA (12 fragment reads per 32 MFMAs instead of 8 per 16) and drops the register staging: operand tiles go
+// global -> LDS by LDS-DMA (16 B per lane, 1 KiB per wave-instruction = 16 rows x 64 B), three stages deep with a
+// counted vmcnt, one barrier per 32-deep k-step.  The DMA writes lane i to LDS chunk i, so the XOR swizzle of the
+// fragment reads is applied on the GLOBAL side: lane (row, physical chunk) fetches logical chunk pc ^ swz(row).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int G2_BM = 256, G2_BN = 128, G2_BK = 32, G2_NBUF = 3;
+constexpr int G2_STAGE = (G2_BM + G2_BN) * G2_BK;  // elements per stage: X tile then W tile
+
+template <int N>
+__device__ __forceinline__ void g2_wait_vm() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+
+__global__ __launch_bounds__(256, 2) void k_gemm_nt_big(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W,
+                                                        int ldw, int M, int N, int Kp, GemmEpi e, int tiles_n) {
+  __shared__ __attribute__((aligned(1024))) bf16 sm[G2_NBUF * G2_STAGE];
+  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
+  const int m0 = tm * G2_BM, n0 = tn * G2_BN;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int l15 = lane & 15, lg = lane >> 4;
+
+  // LDS-DMA sources: wave-instruction j of a stage covers tile rows 16 j .. 16 j + 15 (X: j < 16, W: j < 8)
+  const int lr = lane >> 2, pc = lane & 3;
+  const bf16* gsrc[6];
+  unsigned ldst[6];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const int j = wave + 4 * i, row = 16 * j + lr;
+    gsrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + Swz<32>::chunk(row, pc) * 8;
+    ldst[i] = j * 1024;
+  }
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int j = wave + 4 * i, row = 16 * j + lr;
+    gsrc[4 + i] = W + (size_t)min(n0 + row, N - 1) * ldw + Swz<32>::chunk(row, pc) * 8;
+    ldst[4 + i] = G2_BM * G2_BK * 2 + j * 1024;
+  }
+  const unsigned sm_base = lds_addr(sm);
+#define G2_ISSUE(KT, BUF)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                     \
+      lds_dma16(gsrc[i] + (size_t)(KT) * G2_BK, sm_base + (BUF) * (G2_STAGE * 2) + ldst[i]);
+
+  f32x4 acc[4][8];  // [nt][mt]
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+
+  int fxo[8], fwo[4];
+#pragma unroll
+  for (int t = 0; t < 8; ++t) {
+    const int r = wm * 128 + t * 16 + l15;
+    fxo[t] = r * G2_BK + Swz<32>::chunk(r, lg) * 8;
+  }
+#pragma unroll
+  for (int t = 0; t < 4; ++t) {
+    const int r = wn * 64 + t * 16 + l15;
+    fwo[t] = G2_BM * G2_BK + r * G2_BK + Swz<32>::chunk(r, lg) * 8;
+  }
+
+  const int nk = Kp / G2_BK;
+  G2_ISSUE(0, 0);
+  if (nk > 1) { G2_ISSUE(1, 1); }
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 1 < nk) g2_wait_vm<6>(); else g2_wait_vm<0>();
+    __syncthreads();
+    if (kt + 2 < nk) {
+      const int nb = buf >= 1 ? buf - 1 : 2;  // (kt + 2) % 3
+      G2_ISSUE(kt + 2, nb);
+    }
+    const bf16* st = sm + buf * G2_STAGE;
+    bf16x8 fw[4], fx[8];
+#pragma unroll
+    for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const bf16x8*>(st + fwo[t]);
+#pragma unroll
+    for (int t = 0; t < 8; ++t) fx[t] = *reinterpret_cast<const bf16x8*>(st + fxo[t]);
+#pragma unroll
+    for (int mt = 0; mt < 8; ++mt)
+#pragma unroll
+      for (int nt = 0; nt < 4; ++nt)
+        acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[nt][mt], 0, 0, 0);
+    buf = buf == 2 ? 0 : buf + 1;
+  }
+#undef G2_ISSUE
+
+#pragma unroll
+  for (int mt = 0; mt < 8; ++mt) {
+    const int m = m0 + wm * 128 + mt * 16 + l15;
+    if (m >= M) continue;
+    const float* crow = e.cond ? e.cond + (size_t)(m / e.cond_L) * e.cond_stride + e.cond_off : nullptr;
+#pragma unroll
+    for (int nt = 0; nt < 4; ++nt) {
+      const int n = n0 + wn * 64 + nt * 16 + 4 * lg;
+      if (n >= e.n_store) continue;
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (n < N) {
+        v = make_float4(acc[nt][mt][0], acc[nt][mt][1], acc[nt][mt][2], acc[nt][mt][3]);
+        if (e.bias) {
+          const float4 bb = *reinterpret_cast<const float4*>(e.bias + n);
+          v.x += bb.x; v.y += bb.y; v.z += bb.z; v.w += bb.w;
+        }
+        if (e.act == 1) { v.x = gelu_f(v.x); v.y = gelu_f(v.y); v.z = gelu_f(v.z); v.w = gelu_f(v.w); }
+        if (e.residual) {
+          float4 rr = *reinterpret_cast<const float4*>(e.residual + (size_t)m * e.ldr + n);
+          if (crow) {
+            const float4 sc = *reinterpret_cast<const float4*>(crow + n);
+            const float4 sh = *reinterpret_cast<const float4*>(crow + N + n);
+            rr.x = silu_f(sh.x + rr.x * (sc.x + 1.f)); rr.y = silu_f(sh.y + rr.y * (sc.y + 1.f));
+            rr.z = silu_f(sh.z + rr.z * (sc.z + 1.f)); rr.w = silu_f(sh.w + rr.w * (sc.w + 1.f));
+          }
+          v.x += rr.x; v.y += rr.y; v.z += rr.z; v.w += rr.w;
+        }
+      }
+      if (e.out_f32) {
+        if (n < N) *reinterpret_cast<float4*>(e.out_f32 + (size_t)m * e.ldo + n) = v;
+      } else {
+        *reinterpret_cast<uint2*>(e.out_bf16 + (size_t)m * e.ldo + n) = pack_bf16x4(v.x, v.y, v.z, v.w);
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM on TOKEN-MAJOR operands:  out[Mo, No] += sum_t P[t, m] Q[t, n]   (dW = dY^T X)
 // P = dY (bf16 [rows, ldp]) and Q = X (bf16 [rows, ldq]) are read exactly as the forward / backward kernels wrote them:
 // no transposed copies.  A 32-token x 128-feature tile of each operand goes to LDS row-major (coalesced 16-byte
@@ -377,6 +505,12 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   // BK = 32 halves the LDS footprint (4 workgroups per CU instead of 2): with many row panels in flight the extra
   // residency hides the short-K prologue / epilogue better than the longer k-step amortises its barrier (measured
   // per shape, scripts/bench_gemm.py: +5..25 % for M >= 32k, -3..10 % for M = 8k)
+  const int big_wg = cdiv(M, G2_BM) * tiles_n;
+  if (ee.n_store >= 128 && big_wg >= 384) {
+    hipLaunchKernelGGL(k_gemm_nt_big, dim3(big_wg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n);
+    SWG_LAUNCH_CHECK();
+    return 0;
+  }
   if (Kp % 64 == 0 && M < 16384)
     hipLaunchKernelGGL(k_gemm_nt<64>, dim3(nwg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n, 0, (size_t)0);
   else

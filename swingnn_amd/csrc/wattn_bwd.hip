@@ -5,11 +5,19 @@
 //   dV = P^T dO,  dP = dO V^T,  dS = P (dP - rowsum(P dP)),  dQ = scale dS K,  dK = scale dS^T Q,
 //   d(relative_position_bias_table)[idx(i,j), h] += dS[i,j]
 //
-// First version of the training path: one wavefront per (window, head), fp32 VALU on LDS-resident tiles (the
-// attention core is ~15 % of a block's FLOPs; the four Linear-layer gradients around it run on the MFMA GEMM).
-// Query phase: lane = query row (S, P, dP, dS rows, dQ).  Key phase: lane = key row (dK, dV from the columns of dS
-// and P in LDS, stride 65 -> conflict-free both ways).  A workgroup keeps its head fixed and walks over windows, so
-// the bias-table gradient is accumulated in LDS and flushed with one atomic per entry per workgroup.
+// One wavefront per (window, head), all five contractions on v_mfma_f32_16x16x32_bf16 (head dim padded to 32, the
+// window's tokens to NT = 16 NTL rows):
+//  * Q, K, V, dO rows go global -> registers once (8 head-dim values per lane = an MFMA operand as loaded) and Q, K,
+//    dO also to token-major LDS tiles.
+//  * Phase A, per 16-query tile: S^T = K Q^T and dP^T = V dO^T put the QUERY on the lane (i = lane & 15) and four
+//    consecutive keys in the accumulator registers, so the softmax statistics (max, sum, delta = sum_j P dP) are
+//    in-lane plus two cross-group swaps.  dS in that layout IS the B operand of dQ^T = K^T dS^T (contraction slots
+//    permuted: slot e of lane group g = key 16 jt + 4 g + e); the matching K^T operand is gathered from the token-major
+//    LDS tile with ds_read_b64_tr_b16.  The bias-table gradient is scattered into an LDS copy of the table.
+//  * Phase B, per 16-key tile: S and dP recomputed with swapped operands (KEY on the lane), P and dS rebuilt from
+//    the per-query statistics (LDS), then dK^T = Q^T dS and dV^T = dO^T P the same way.
+// A workgroup keeps its head fixed and walks over windows, so the bias-table gradient is flushed with one atomic per
+// entry per workgroup.
 #include "common.h"
 
 namespace {
@@ -22,174 +30,247 @@ struct WbArgs {
   float* drpb;
   int B, res, win, shift, heads, C, hd;
   float scale;
-  int nr;  // LDS tile rows: ceil16(win * win)
 };
 
-constexpr int HDP = 32;     // padded head dim
-constexpr int PLD = 65;     // row stride of the n x n matrices
+constexpr int LDT = 48;     // LDS row stride (elements) of the token-major tiles: 8 rows x 32 B cover 64 banks once
 constexpr int NBMAX = 232;  // >= (2*8-1)^2
 
-__device__ __forceinline__ void load_row(const bf16* p, int hd, float* r) {
-#pragma unroll
-  for (int d = 0; d < HDP; d += 4) {
-    if (d < hd) {
-      const uint2 raw = *reinterpret_cast<const uint2*>(p + d);
-      const bf16x4 v = *reinterpret_cast<const bf16x4*>(&raw);
-      r[d] = (float)v[0]; r[d + 1] = (float)v[1]; r[d + 2] = (float)v[2]; r[d + 3] = (float)v[3];
-    } else {
-      r[d] = r[d + 1] = r[d + 2] = r[d + 3] = 0.f;
-    }
-  }
+typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+__device__ __forceinline__ bf16x4 tr4(const bf16* p) { return __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)p); }
+
+// 8 head-dim values of one row (two 8-byte pieces; `rem` = values left in the head from this lane's first column)
+__device__ __forceinline__ bf16x8 load8(const bf16* p, bool valid, int rem) {
+  uint2 lo = make_uint2(0u, 0u), hi = make_uint2(0u, 0u);
+  if (valid && rem >= 4) lo = *reinterpret_cast<const uint2*>(p);
+  if (valid && rem >= 8) hi = *reinterpret_cast<const uint2*>(p + 4);
+  uint4 v = make_uint4(lo.x, lo.y, hi.x, hi.y);
+  return *reinterpret_cast<bf16x8*>(&v);
 }
-__device__ __forceinline__ void put_row(float* dst, const float* r) {
-#pragma unroll
-  for (int d = 0; d < HDP; d += 4) *reinterpret_cast<float4*>(dst + d) = make_float4(r[d], r[d + 1], r[d + 2], r[d + 3]);
+__device__ __forceinline__ bf16x8 pack8(const f32x4& a, const f32x4& b) {
+  return (bf16x8){(bf16)a[0], (bf16)a[1], (bf16)a[2], (bf16)a[3], (bf16)b[0], (bf16)b[1], (bf16)b[2], (bf16)b[3]};
 }
-__device__ __forceinline__ void store_row(bf16* p, int hd, const float* r, float k) {
-#pragma unroll
-  for (int d = 0; d < HDP; d += 4)
-    if (d < hd) *reinterpret_cast<uint2*>(p + d) = pack_bf16x4(r[d] * k, r[d + 1] * k, r[d + 2] * k, r[d + 3] * k);
+__device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
+  return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
+template <int NTL>
 __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
-  extern __shared__ __attribute__((aligned(16))) float sm[];
-  // rows of the per-window tiles: NR = ceil16(tokens per window), so that small windows (4x4: 9 KB instead of 66 KB)
-  // leave room for many workgroups per CU
-  const int NR = a.nr;
-  float* Ks = sm;
-  float* Vs = Ks + NR * HDP;
-  float* Qs = Vs + NR * HDP;
-  float* Ds = Qs + NR * HDP;
-  float* Pm = Ds + NR * HDP;
-  float* Sm = Pm + NR * PLD;
-  float* bias = Sm + NR * PLD;
-  float* dbias = bias + NBMAX;
-  int* rid = reinterpret_cast<int*>(dbias + NBMAX);
+  constexpr int NT = 16 * NTL;
+  constexpr int KP = (NTL + 1) / 2;  // 32-deep contraction steps over the window's tokens
+  __shared__ __attribute__((aligned(16))) bf16 Qs[NT * LDT];
+  __shared__ __attribute__((aligned(16))) bf16 Ks[NT * LDT];
+  __shared__ __attribute__((aligned(16))) bf16 Ds[NT * LDT];
+  __shared__ float bias[NBMAX];
+  __shared__ float dbias[NBMAX];
+  __shared__ __attribute__((aligned(16))) float st_m[64];
+  __shared__ __attribute__((aligned(16))) float st_inv[64];
+  __shared__ __attribute__((aligned(16))) float st_delta[64];
+  __shared__ __attribute__((aligned(16))) int rid[64];
+  __shared__ __attribute__((aligned(16))) int pos[64];
 
-  const int lane = threadIdx.x;
+  const int lane = threadIdx.x, l15 = lane & 15, lg = lane >> 4, q4 = l15 >> 2, p4 = l15 & 3;
   const int h = blockIdx.x;
   const int n = a.win * a.win, w2 = 2 * a.win - 1, nb = w2 * w2;
   const int nwx = a.res / a.win, nW = nwx * nwx, Ltok = a.res * a.res;
   const int hc = h * a.hd;
+  const int cpos = (a.win - 1) * (w2 + 1);
+  const f32x4 zero4 = {0.f, 0.f, 0.f, 0.f};
+  const bf16x4 zb4 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
   for (int t = lane; t < nb; t += 64) {
     bias[t] = a.rpb[(size_t)t * a.heads + h];
     dbias[t] = 0.f;
   }
-  const int il = min(lane, n - 1);
-  const int iy = il / a.win, ix = il - iy * a.win;
-  const bool act = lane < n;
+  {  // index (iy - jy + w - 1) (2w - 1) + (ix - jx + w - 1) = cpos + pos[i] - pos[j]   (swin_gnn.py:88-97)
+    const int t = min(lane, n - 1);
+    const int ty = t / a.win;
+    pos[lane] = ty * w2 + (t - ty * a.win);
+  }
+  // this lane's own rows: local token 16 t + l15 of every tile t
+  int ry_[NTL], rx_[NTL], rpos[NTL];
+  bool rvalid[NTL];
+#pragma unroll
+  for (int t = 0; t < NTL; ++t) {
+    const int il = min(16 * t + l15, n - 1);
+    ry_[t] = il / a.win;
+    rx_[t] = il - ry_[t] * a.win;
+    rpos[t] = ry_[t] * w2 + rx_[t];
+    rvalid[t] = 16 * t + l15 < n;
+  }
+  const int rem = a.hd - 8 * lg;
+  const int troff = (4 * lg + q4) * LDT + 4 * p4;  // transposed-read address of this lane inside a 16-row tile
 
   for (int u = blockIdx.y; u < a.B * nW; u += gridDim.y) {
     const int b = u / nW, wi = u - b * nW;
     const int wy = wi / nwx, wx = wi - wy * nwx;
-    const int ys = wy * a.win + iy, xs = wx * a.win + ix;
-    int y = ys + a.shift, x = xs + a.shift;
-    if (y >= a.res) y -= a.res;
-    if (x >= a.res) x -= a.res;
-    const size_t tok = (size_t)b * Ltok + y * a.res + x;
-    int myrid = 0;
-    if (a.shift > 0) {
-      const int ry = ys < a.res - a.win ? 0 : (ys < a.res - a.shift ? 1 : 2);
-      const int rx = xs < a.res - a.win ? 0 : (xs < a.res - a.shift ? 1 : 2);
-      myrid = 3 * ry + rx;
+    size_t tok[NTL];
+    int myrid[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const int ys = wy * a.win + ry_[t], xs = wx * a.win + rx_[t];
+      int y = ys + a.shift, x = xs + a.shift;
+      if (y >= a.res) y -= a.res;
+      if (x >= a.res) x -= a.res;
+      tok[t] = (size_t)b * Ltok + y * a.res + x;
+      myrid[t] = 0;
+      if (a.shift > 0) {
+        const int ry = ys < a.res - a.win ? 0 : (ys < a.res - a.shift ? 1 : 2);
+        const int rx = xs < a.res - a.win ? 0 : (xs < a.res - a.shift ? 1 : 2);
+        myrid[t] = 3 * ry + rx;
+      }
+    }
+    bf16x8 fq[NTL], fk[NTL], fv[NTL], fd[NTL];
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const bf16* row = a.qkv + tok[t] * a.ldq + hc + 8 * lg;
+      fq[t] = load8(row, rvalid[t], rem);
+      fk[t] = load8(row + a.C, rvalid[t], rem);
+      fv[t] = load8(row + 2 * a.C, rvalid[t], rem);
+      fd[t] = load8(a.dO + tok[t] * a.ldo + hc + 8 * lg, rvalid[t], rem);
     }
     __syncthreads();  // the previous window's LDS reads are done
-    rid[lane] = myrid;
-    float q[HDP], go[HDP];
-    {
-      float t[HDP];
-      const bf16* row = a.qkv + tok * a.ldq + hc;
-      load_row(row, act ? a.hd : 0, q);
-      load_row(a.dO + tok * a.ldo + hc, act ? a.hd : 0, go);
-      if (lane < NR) {
-        put_row(Qs + lane * HDP, q);
-        load_row(row + a.C, act ? a.hd : 0, t);
-        put_row(Ks + lane * HDP, t);
-        load_row(row + 2 * a.C, act ? a.hd : 0, t);
-        put_row(Vs + lane * HDP, t);
-        put_row(Ds + lane * HDP, go);
-      }
+#pragma unroll
+    for (int t = 0; t < NTL; ++t) {
+      const int o = (16 * t + l15) * LDT + 8 * lg;
+      *reinterpret_cast<bf16x8*>(&Qs[o]) = fq[t];
+      *reinterpret_cast<bf16x8*>(&Ks[o]) = fk[t];
+      *reinterpret_cast<bf16x8*>(&Ds[o]) = fd[t];
+      if (lg == 0) rid[16 * t + l15] = myrid[t];
     }
     __syncthreads();
 
-    bf16* drow = a.dqkv + tok * a.lddq + hc;
-    if (act) {  // ---- query phase ----
-      float* Sr = Sm + lane * PLD;
-      float* Pr = Pm + lane * PLD;
-      float mx = -3.0e38f;
-      for (int j = 0; j < n; ++j) {
-        const float4* kr = reinterpret_cast<const float4*>(Ks + j * HDP);
-        float s = 0.f;
+    // ---------------- phase A: query on the lane -> statistics, dQ, bias-table gradient ----------------
 #pragma unroll
-        for (int d4 = 0; d4 < HDP / 4; ++d4) {
-          const float4 kv = kr[d4];
-          s += q[4 * d4] * kv.x + q[4 * d4 + 1] * kv.y + q[4 * d4 + 2] * kv.z + q[4 * d4 + 3] * kv.w;
+    for (int it = 0; it < NTL; ++it) {
+      f32x4 sv[NTL], dp[NTL];
+      int idx[NTL][4];
+#pragma unroll
+      for (int jt = 0; jt < NTL; ++jt) {
+        sv[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt], fq[it], zero4, 0, 0, 0);
+        dp[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fv[jt], fd[it], zero4, 0, 0, 0);
+      }
+      const int pi = cpos + rpos[it];
+      float mx = -3.0e38f;
+#pragma unroll
+      for (int jt = 0; jt < NTL; ++jt) {
+        const int4 pj = *reinterpret_cast<const int4*>(&pos[16 * jt + 4 * lg]);
+        const int4 rj = *reinterpret_cast<const int4*>(&rid[16 * jt + 4 * lg]);
+        const int pjv[4] = {pj.x, pj.y, pj.z, pj.w}, rjv[4] = {rj.x, rj.y, rj.z, rj.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const int id = pi - pjv[r];
+          float v = sv[jt][r] * a.scale + bias[id];
+          if (a.shift > 0 && rjv[r] != myrid[it]) v += -100.0f;  // swin_gnn.py:226
+          if (16 * jt + 4 * lg + r >= n) v = -3.0e38f;
+          sv[jt][r] = v;
+          idx[jt][r] = id;
+          mx = fmaxf(mx, v);
         }
-        const int jy = j / a.win, jx = j - jy * a.win;
-        s = s * a.scale + bias[(iy - jy + a.win - 1) * w2 + (ix - jx + a.win - 1)];
-        if (a.shift > 0 && rid[j] != myrid) s += -100.0f;  // swin_gnn.py:226
-        Sr[j] = s;
-        mx = fmaxf(mx, s);
       }
+      mx = rows_max(mx);
       float sum = 0.f;
-      for (int j = 0; j < n; ++j) {
-        const float e = __expf(Sr[j] - mx);
-        Pr[j] = e;
-        sum += e;
-      }
+#pragma unroll
+      for (int jt = 0; jt < NTL; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float e = __expf(sv[jt][r] - mx);
+          sv[jt][r] = e;
+          sum += e;
+        }
+      sum = rows_sum(sum);
       const float inv = 1.0f / sum;
       float delta = 0.f;
-      for (int j = 0; j < n; ++j) {
-        const float4* vr = reinterpret_cast<const float4*>(Vs + j * HDP);
-        float dp = 0.f;
 #pragma unroll
-        for (int d4 = 0; d4 < HDP / 4; ++d4) {
-          const float4 vv = vr[d4];
-          dp += go[4 * d4] * vv.x + go[4 * d4 + 1] * vv.y + go[4 * d4 + 2] * vv.z + go[4 * d4 + 3] * vv.w;
+      for (int jt = 0; jt < NTL; ++jt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          const float p = sv[jt][r] * inv;
+          sv[jt][r] = p;
+          delta += p * dp[jt][r];
         }
-        const float p = Pr[j] * inv;
-        Pr[j] = p;
-        Sr[j] = dp;
-        delta += p * dp;
+      delta = rows_sum(delta);
+      if (lg == 0) {
+        st_m[16 * it + l15] = mx;
+        st_inv[16 * it + l15] = rvalid[it] ? inv : 0.f;
+        st_delta[16 * it + l15] = delta;
       }
-      float dq[HDP];
 #pragma unroll
-      for (int d = 0; d < HDP; ++d) dq[d] = 0.f;
-      for (int j = 0; j < n; ++j) {
-        const float ds = Pr[j] * (Sr[j] - delta);
-        Sr[j] = ds;
-        const float4* kr = reinterpret_cast<const float4*>(Ks + j * HDP);
+      for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
-        for (int d4 = 0; d4 < HDP / 4; ++d4) {
-          const float4 kv = kr[d4];
-          dq[4 * d4] += ds * kv.x; dq[4 * d4 + 1] += ds * kv.y; dq[4 * d4 + 2] += ds * kv.z; dq[4 * d4 + 3] += ds * kv.w;
+        for (int r = 0; r < 4; ++r) {
+          const float ds = rvalid[it] ? sv[jt][r] * (dp[jt][r] - delta) : 0.f;
+          dp[jt][r] = ds;
+          atomicAdd(&dbias[idx[jt][r]], ds);
         }
-        const int jy = j / a.win, jx = j - jy * a.win;
-        // one wavefront per workgroup and the lanes of one step hit distinct table entries: plain read-modify-write
-        dbias[(iy - jy + a.win - 1) * w2 + (ix - jx + a.win - 1)] += ds;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f32x4 acc = zero4;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+          const int j0 = 2 * kp, j1 = 2 * kp + 1;
+          const bf16x8 bop = pack8(dp[j0], j1 < NTL ? dp[j1 < NTL ? j1 : 0] : zero4);
+          const bf16x4 a0 = tr4(&Ks[16 * j0 * LDT + troff + 16 * dt]);
+          const bf16x4 a1 = j1 < NTL ? tr4(&Ks[16 * (j1 < NTL ? j1 : 0) * LDT + troff + 16 * dt]) : zb4;
+          acc = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(a0, a1), bop, acc, 0, 0, 0);
+        }
+        if (rvalid[it] && 16 * dt + 4 * lg < a.hd)
+          *reinterpret_cast<uint2*>(a.dqkv + tok[it] * a.lddq + hc + 16 * dt + 4 * lg) =
+              pack_bf16x4(acc[0] * a.scale, acc[1] * a.scale, acc[2] * a.scale, acc[3] * a.scale);
       }
-      store_row(drow, a.hd, dq, a.scale);
     }
-    __syncthreads();
-    if (act) {  // ---- key phase ----
-      float dk[HDP], dv[HDP];
+    __syncthreads();  // statistics visible
+
+    // ---------------- phase B: key on the lane -> dK, dV ----------------
 #pragma unroll
-      for (int d = 0; d < HDP; ++d) dk[d] = dv[d] = 0.f;
-      for (int i = 0; i < n; ++i) {
-        const float ds = Sm[i * PLD + lane], p = Pm[i * PLD + lane];
-        const float4* qr = reinterpret_cast<const float4*>(Qs + i * HDP);
-        const float4* gr = reinterpret_cast<const float4*>(Ds + i * HDP);
+    for (int jt = 0; jt < NTL; ++jt) {
+      f32x4 sv[NTL], dp[NTL];
 #pragma unroll
-        for (int d4 = 0; d4 < HDP / 4; ++d4) {
-          const float4 qv = qr[d4], gv = gr[d4];
-          dk[4 * d4] += ds * qv.x; dk[4 * d4 + 1] += ds * qv.y; dk[4 * d4 + 2] += ds * qv.z; dk[4 * d4 + 3] += ds * qv.w;
-          dv[4 * d4] += p * gv.x; dv[4 * d4 + 1] += p * gv.y; dv[4 * d4 + 2] += p * gv.z; dv[4 * d4 + 3] += p * gv.w;
+      for (int it = 0; it < NTL; ++it) {
+        sv[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fq[it], fk[jt], zero4, 0, 0, 0);
+        dp[it] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fd[it], fv[jt], zero4, 0, 0, 0);
+      }
+      const int pj = rpos[jt] - cpos;
+#pragma unroll
+      for (int it = 0; it < NTL; ++it) {
+        const int4 pi4 = *reinterpret_cast<const int4*>(&pos[16 * it + 4 * lg]);
+        const int4 ri4 = *reinterpret_cast<const int4*>(&rid[16 * it + 4 * lg]);
+        const float4 m4 = *reinterpret_cast<const float4*>(&st_m[16 * it + 4 * lg]);
+        const float4 i4 = *reinterpret_cast<const float4*>(&st_inv[16 * it + 4 * lg]);
+        const float4 d4 = *reinterpret_cast<const float4*>(&st_delta[16 * it + 4 * lg]);
+        const int piv[4] = {pi4.x, pi4.y, pi4.z, pi4.w}, riv[4] = {ri4.x, ri4.y, ri4.z, ri4.w};
+        const float mv[4] = {m4.x, m4.y, m4.z, m4.w}, iv[4] = {i4.x, i4.y, i4.z, i4.w}, dv_[4] = {d4.x, d4.y, d4.z, d4.w};
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          float v = sv[it][r] * a.scale + bias[piv[r] - pj];
+          if (a.shift > 0 && riv[r] != myrid[jt]) v += -100.0f;
+          const float p = rvalid[jt] ? __expf(v - mv[r]) * iv[r] : 0.f;
+          sv[it][r] = p;
+          dp[it][r] = p * (dp[it][r] - dv_[r]);
         }
       }
-      store_row(drow + a.C, a.hd, dk, a.scale);
-      store_row(drow + 2 * a.C, a.hd, dv, 1.0f);
-      if (h == 0)  // K padding of the following GEMM operand
-        for (int c = 3 * a.C; c < a.lddq; c += 4) *reinterpret_cast<uint2*>(a.dqkv + tok * a.lddq + c) = make_uint2(0u, 0u);
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        f32x4 ak = zero4, av = zero4;
+#pragma unroll
+        for (int kp = 0; kp < KP; ++kp) {
+          const int i0 = 2 * kp, i1 = 2 * kp + 1;
+          const int i1c = i1 < NTL ? i1 : 0;
+          const bf16x8 bds = pack8(dp[i0], i1 < NTL ? dp[i1c] : zero4);
+          const bf16x8 bp = pack8(sv[i0], i1 < NTL ? sv[i1c] : zero4);
+          const bf16x4 q0 = tr4(&Qs[16 * i0 * LDT + troff + 16 * dt]);
+          const bf16x4 q1 = i1 < NTL ? tr4(&Qs[16 * i1c * LDT + troff + 16 * dt]) : zb4;
+          const bf16x4 g0 = tr4(&Ds[16 * i0 * LDT + troff + 16 * dt]);
+          const bf16x4 g1 = i1 < NTL ? tr4(&Ds[16 * i1c * LDT + troff + 16 * dt]) : zb4;
+          ak = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(q0, q1), bds, ak, 0, 0, 0);
+          av = __builtin_amdgcn_mfma_f32_16x16x32_bf16(cat8(g0, g1), bp, av, 0, 0, 0);
+        }
+        if (rvalid[jt] && 16 * dt + 4 * lg < a.hd) {
+          bf16* o = a.dqkv + tok[jt] * a.lddq + hc + 16 * dt + 4 * lg;
+          *reinterpret_cast<uint2*>(o + a.C) = pack_bf16x4(ak[0] * a.scale, ak[1] * a.scale, ak[2] * a.scale, ak[3] * a.scale);
+          *reinterpret_cast<uint2*>(o + 2 * a.C) = pack_bf16x4(av[0], av[1], av[2], av[3]);
+        }
+      }
+      if (h == 0 && lg == 0 && rvalid[jt])  // K padding of the following GEMM operand
+        for (int c = 3 * a.C; c < a.lddq; c += 4) *reinterpret_cast<uint2*>(a.dqkv + tok[jt] * a.lddq + c) = make_uint2(0u, 0u);
     }
   }
   __syncthreads();
@@ -208,21 +289,18 @@ int launch_wattn_bwd(const bf16* qkv, int ldq, const bf16* dO, int ldo, int B, i
   if (n > 64 || hd > 32 || hd % 4 || ldq % 4 || ldo % 4 || lddq % 4 || C % 4 || win > 8) return SWG_E_UNSUPPORTED;
   if (shift < 0 || shift >= win) return SWG_E_SHAPE;
   if (!qkv || !dO || !dqkv || !rpb || !drpb) return SWG_E_NULL;
-  const int nr = round_up(n, 16);
-  WbArgs a = {qkv, ldq, dO, ldo, dqkv, lddq, rpb, drpb, B, res, win, shift, heads, C, hd, 1.0f / sqrtf((float)hd), nr};
-  const size_t lds = (size_t)(4 * nr * HDP + 2 * nr * PLD + 2 * NBMAX + 64) * sizeof(float);
-  const size_t lds_max = (size_t)(4 * 64 * HDP + 2 * 64 * PLD + 2 * NBMAX + 64) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_bwd, hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds_max);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  WbArgs a = {qkv, ldq, dO, ldo, dqkv, lddq, rpb, drpb, B, res, win, shift, heads, C, hd, 1.0f / sqrtf((float)hd)};
   const int nW = (res / win) * (res / win);
   const int gy = max(1, min(B * nW, cdiv(4096, heads)));
   const double T = (double)B * res * res;
   SwgProfScope ps(KID_WATTN_BWD, 10.0 * n * C * T, T * (3.0 * C * 2 + C * 2 + 3.0 * C * 2), s);
-  hipLaunchKernelGGL(k_wattn_bwd, dim3(heads, gy), dim3(64), lds, s, a);
+  const dim3 grid(heads, gy), block(64);
+  switch (cdiv(n, 16)) {
+    case 1: hipLaunchKernelGGL(k_wattn_bwd<1>, grid, block, 0, s, a); break;
+    case 2: hipLaunchKernelGGL(k_wattn_bwd<2>, grid, block, 0, s, a); break;
+    case 3: hipLaunchKernelGGL(k_wattn_bwd<3>, grid, block, 0, s, a); break;
+    default: hipLaunchKernelGGL(k_wattn_bwd<4>, grid, block, 0, s, a); break;
+  }
   SWG_LAUNCH_CHECK();
   return 0;
 }
