@@ -312,15 +312,21 @@ constexpr int TN_BT = 32;    // tokens per k-step
 constexpr int TN_LD = 144;   // LDS row stride in elements
 
 __global__ __launch_bounds__(256) void k_gemm_tn(const bf16* __restrict__ P, int ldp, const bf16* __restrict__ Q, int ldq,
-                                                 int rows, int Mo, int No, float* __restrict__ out, int tiles_n, int kslice,
-                                                 size_t out_slice, int accumulate) {
+                                                 int rows, int Mo, int No, float* __restrict__ out, int tiles_n, int tiles,
+                                                 int nslices, int kslice, size_t out_slice, int accumulate) {
   __shared__ __attribute__((aligned(16))) bf16 sP[2][TN_BT * TN_LD];
   __shared__ __attribute__((aligned(16))) bf16 sQ[2][TN_BT * TN_LD];
-  const int tile = xcd_remap(blockIdx.x, gridDim.x);
+  // 1-D grid over (token slice, tile): workgroup L runs on XCD L % 8, so slice = xcd + 8 (slot / tiles) keeps all
+  // tiles of one token slice on ONE XCD, back to back: every operand byte is fetched from HBM once and the other
+  // tiles of the slice hit that XCD's L2
+  const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
+  const int sl = xcd + 8 * (slot / tiles);
+  if (sl >= nslices) return;
+  const int tile = slot % tiles;
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * 128, n0 = tn * 128;
-  const int t_begin = blockIdx.y * kslice, t_end = min(rows, t_begin + kslice);
-  float* dst = out + (size_t)blockIdx.y * out_slice;
+  const int t_begin = sl * kslice, t_end = min(rows, t_begin + kslice);
+  float* dst = out + (size_t)sl * out_slice;
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
@@ -469,19 +475,22 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
   if (!P || !Q || !out) return SWG_E_NULL;
   const int tiles_m = cdiv(Mo, 128), tiles_n = cdiv(No, 128);
   const int tiles = tiles_m * tiles_n;
-  int S = min(min(cdiv(512, tiles), max(rows / 256, 1)), 64);
+  int S = min(min(cdiv(1024, tiles), max(rows / 256, 1)), 256);
+  while (S > 1 && (size_t)S * Mo * No > partial_floats) --S;
   int kslice = round_up(cdiv(rows, S), TN_BT);
   S = cdiv(rows, kslice);
   SwgProfScope ps(KID_GEMM, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
                                                            8.0 * Mo * (double)No, s);
   if (S <= 1) {
-    hipLaunchKernelGGL(k_gemm_tn, dim3(tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, kslice, (size_t)0, 1);
+    hipLaunchKernelGGL(k_gemm_tn, dim3(8 * tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, tiles, 1, kslice,
+                       (size_t)0, 1);
     SWG_LAUNCH_CHECK();
     return 0;
   }
   const size_t slice = (size_t)Mo * No;
   if (!partial || partial_floats < slice * S) return SWG_E_WORKSPACE;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles, S), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n, kslice, slice, 0);
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n,
+                     tiles, S, kslice, slice, 0);
   SWG_LAUNCH_CHECK();
   const size_t n4 = slice / 4;
   hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)min((size_t)1024, (n4 + 255) / 256)), dim3(256), 0, s, partial, S, n4,
@@ -506,7 +515,9 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   // residency hides the short-K prologue / epilogue better than the longer k-step amortises its barrier (measured
   // per shape, scripts/bench_gemm.py: +5..25 % for M >= 32k, -3..10 % for M = 8k)
   const int big_wg = cdiv(M, G2_BM) * tiles_n;
-  if (ee.n_store >= 128 && big_wg >= 384) {
+  // measured per shape (scripts/bench_gemm.py, B = 112): the large form wins for wide outputs and for very long token
+  // panels; short-K fp32 + residual shapes (epilogue-bound) keep the small form's higher workgroup residency
+  if (big_wg >= 384 && (ee.n_store >= 1024 || M >= 131072)) {
     hipLaunchKernelGGL(k_gemm_nt_big, dim3(big_wg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n);
     SWG_LAUNCH_CHECK();
     return 0;

@@ -53,7 +53,7 @@ __device__ __forceinline__ bf16x8 cat8(const bf16x4& a, const bf16x4& b) {
   return (bf16x8){a[0], a[1], a[2], a[3], b[0], b[1], b[2], b[3]};
 }
 
-template <int NTL>
+template <int NTL, bool SH>
 __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
   constexpr int NT = 16 * NTL;
   constexpr int KP = (NTL + 1) / 2;  // 32-deep contraction steps over the window's tokens
@@ -112,7 +112,7 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
       if (x >= a.res) x -= a.res;
       tok[t] = (size_t)b * Ltok + y * a.res + x;
       myrid[t] = 0;
-      if (a.shift > 0) {
+      if (SH) {
         const int ry = ys < a.res - a.win ? 0 : (ys < a.res - a.shift ? 1 : 2);
         const int rx = xs < a.res - a.win ? 0 : (xs < a.res - a.shift ? 1 : 2);
         myrid[t] = 3 * ry + rx;
@@ -159,8 +159,8 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int id = pi - pjv[r];
           float v = sv[jt][r] * a.scale + bias[id];
-          if (a.shift > 0 && rjv[r] != myrid[it]) v += -100.0f;  // swin_gnn.py:226
-          if (16 * jt + 4 * lg + r >= n) v = -3.0e38f;
+          if (SH && rjv[r] != myrid[it]) v += -100.0f;  // swin_gnn.py:226
+          if (jt == NTL - 1 && 16 * jt + 4 * lg + r >= n) v = -3.0e38f;  // padding keys: only in the last tile
           sv[jt][r] = v;
           idx[jt][r] = id;
           mx = fmaxf(mx, v);
@@ -177,7 +177,7 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
           sum += e;
         }
       sum = rows_sum(sum);
-      const float inv = 1.0f / sum;
+      const float inv = rvalid[it] ? 1.0f / sum : 0.f;  // padding queries: P = dS = 0
       float delta = 0.f;
 #pragma unroll
       for (int jt = 0; jt < NTL; ++jt)
@@ -190,14 +190,14 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
       delta = rows_sum(delta);
       if (lg == 0) {
         st_m[16 * it + l15] = mx;
-        st_inv[16 * it + l15] = rvalid[it] ? inv : 0.f;
+        st_inv[16 * it + l15] = inv;
         st_delta[16 * it + l15] = delta;
       }
 #pragma unroll
       for (int jt = 0; jt < NTL; ++jt)
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
-          const float ds = rvalid[it] ? sv[jt][r] * (dp[jt][r] - delta) : 0.f;
+          const float ds = sv[jt][r] * (dp[jt][r] - delta);
           dp[jt][r] = ds;
           atomicAdd(&dbias[idx[jt][r]], ds);
         }
@@ -241,8 +241,9 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           float v = sv[it][r] * a.scale + bias[piv[r] - pj];
-          if (a.shift > 0 && riv[r] != myrid[jt]) v += -100.0f;
-          const float p = rvalid[jt] ? __expf(v - mv[r]) * iv[r] : 0.f;
+          if (SH && riv[r] != myrid[jt]) v += -100.0f;
+          float p = __expf(v - mv[r]) * iv[r];
+          if (jt == NTL - 1 && !rvalid[jt]) p = 0.f;  // padding keys
           sv[it][r] = p;
           dp[it][r] = p * (dp[it][r] - dv_[r]);
         }
@@ -295,12 +296,16 @@ int launch_wattn_bwd(const bf16* qkv, int ldq, const bf16* dO, int ldo, int B, i
   const double T = (double)B * res * res;
   SwgProfScope ps(KID_WATTN_BWD, 10.0 * n * C * T, T * (3.0 * C * 2 + C * 2 + 3.0 * C * 2), s);
   const dim3 grid(heads, gy), block(64);
+#define WB_LAUNCH(NTL)                                                                     \
+  if (shift > 0) hipLaunchKernelGGL((k_wattn_bwd<NTL, true>), grid, block, 0, s, a);       \
+  else hipLaunchKernelGGL((k_wattn_bwd<NTL, false>), grid, block, 0, s, a);
   switch (cdiv(n, 16)) {
-    case 1: hipLaunchKernelGGL(k_wattn_bwd<1>, grid, block, 0, s, a); break;
-    case 2: hipLaunchKernelGGL(k_wattn_bwd<2>, grid, block, 0, s, a); break;
-    case 3: hipLaunchKernelGGL(k_wattn_bwd<3>, grid, block, 0, s, a); break;
-    default: hipLaunchKernelGGL(k_wattn_bwd<4>, grid, block, 0, s, a); break;
+    case 1: WB_LAUNCH(1); break;
+    case 2: WB_LAUNCH(2); break;
+    case 3: WB_LAUNCH(3); break;
+    default: WB_LAUNCH(4); break;
   }
+#undef WB_LAUNCH
   SWG_LAUNCH_CHECK();
   return 0;
 }
