@@ -92,12 +92,11 @@ int wattn_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const
   if ((r = launch_gemm(xn, Cp, (const bf16*)blk->qkv.w, T, 3 * C, Cp, e, s))) return r;
   if ((r = launch_wattn_core(qkv, ldq, B, blk->res, blk->win, blk->shift, blk->heads, C, blk->rpb, o, Cp, s))) return r;
   // ---- proj (:137): dO = dy Wproj, dWproj += dy^T o, dbproj += colsum(dy) ----
-  if ((r = launch_cast_pad(dy, T, C, C, dyb, Cp, s))) return r;
+  if ((r = launch_cast_pad_colsum(dy, T, C, C, dyb, Cp, tr->proj.db, s))) return r;
   GemmEpi e1 = {};
   e1.out_bf16 = dO; e1.ldo = Cp; e1.n_store = Cp;
   if ((r = launch_gemm(dyb, Cp, (const bf16*)tr->proj.wt, T, C, Cp, e1, s))) return r;
   if ((r = wgrad_tn(dyb, Cp, C, o, Cp, C, T, tr->proj.dw, w, s))) return r;
-  if ((r = launch_colsum_f32(dy, T, C, C, tr->proj.db, s))) return r;
   // ---- attention core ----
   if ((r = launch_wattn_bwd(qkv, ldq, dO, Cp, B, blk->res, blk->win, blk->shift, blk->heads, C, blk->rpb, dqkv, Q3p,
                             tr->drpb, s)))
@@ -136,19 +135,17 @@ int mlp_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const f
   if ((r = launch_gemm(xn, Cp, (const bf16*)blk->fc1.w, T, H, Cp, e, s))) return r;
   if ((r = launch_gelu_fwd(h, a, (size_t)T * Hp, s))) return r;
   // ---- fc2 ----
-  if ((r = launch_cast_pad(dy, T, C, C, dyb, Cp, s))) return r;
+  if ((r = launch_cast_pad_colsum(dy, T, C, C, dyb, Cp, tr->fc2.db, s))) return r;
   GemmEpi e1 = {};
   e1.out_bf16 = da; e1.ldo = Hp; e1.n_store = Hp;
   if ((r = launch_gemm(dyb, Cp, (const bf16*)tr->fc2.wt, T, H, Cp, e1, s))) return r;
   if ((r = wgrad_tn(dyb, Cp, C, a, Hp, H, T, tr->fc2.dw, w, s))) return r;
-  if ((r = launch_colsum_f32(dy, T, C, C, tr->fc2.db, s))) return r;
   // ---- GELU, fc1 ----
-  if ((r = launch_gelu_bwd(h, da, da, (size_t)T * Hp, s))) return r;
+  if ((r = launch_gelu_bwd_colsum(h, da, da, T, H, Hp, tr->fc1.db, s))) return r;
   GemmEpi e2 = {};
   e2.out_f32 = dxn; e2.ldo = C;
   if ((r = launch_gemm(da, Hp, (const bf16*)tr->fc1.wt, T, C, Hp, e2, s))) return r;
   if ((r = wgrad_tn(da, Hp, H, xn, Cp, C, T, tr->fc1.dw, w, s))) return r;
-  if ((r = launch_colsum_bf16(da, T, H, Hp, tr->fc1.db, s))) return r;
   // ---- LN2 + residual ----
   return launch_ln_bwd(x_in, dxn, blk->ln2.g, dy, T, C, dx, tr->ln2.dg, tr->ln2.db, s);
 }
@@ -324,13 +321,12 @@ int na_head_bwd(const swg_lin& fc1, const swg_lin_train& t1, const float* w2, fl
   if ((r = wgrad(dy, nullptr, Co, Co, act, Cp, C0, rows, dw2, w, s))) return r;
   if ((r = launch_colsum_f32(dy, rows, Co, Co, db2, s))) return r;
   if ((r = launch_na_head_bwd(dy, w2, rows, C0, Co, act, Cp, s))) return r;   // act now holds d(act)
-  if ((r = launch_gelu_bwd(pre, act, act, (size_t)rows * Cp, s))) return r;   // ... and now d(pre)
+  if ((r = launch_gelu_bwd_colsum(pre, act, act, rows, C0, Cp, t1.db, s))) return r;   // ... and now d(pre); db1 too
   GemmEpi e2 = {};
   e2.out_f32 = din; e2.ldo = C0;
   if (accumulate) { e2.residual = din; e2.ldr = C0; }
   if ((r = launch_gemm(act, Cp, (const bf16*)t1.wt, rows, C0, Cp, e2, s))) return r;
-  if ((r = wgrad_tn(act, Cp, C0, in, Cp, C0, rows, t1.dw, w, s))) return r;
-  return launch_colsum_bf16(act, rows, C0, Cp, t1.db, s);
+  return wgrad_tn(act, Cp, C0, in, Cp, C0, rows, t1.dw, w, s);
 }
 
 int na_readout_bwd_impl(const swg_net* net, const swg_nodeadj* na, const swg_nodeadj_train* tr, int B, const float* tok,

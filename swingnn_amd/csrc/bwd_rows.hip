@@ -92,6 +92,75 @@ __global__ __launch_bounds__(256) void k_gelu_bwd(const bf16* __restrict__ h, co
   }
 }
 
+// ---- fused forms: the bf16 GEMM operand AND the bias gradient from one read of the gradient ----
+// workgroup = 16 column chunks x 16 row phases over `rpb` rows; column sums folded through LDS, one atomic per column
+// cast: fp32 dy [rows, C] -> bf16 [rows, ldo] (columns [C, ldo) zero), db[c] += sum_rows dy
+__global__ __launch_bounds__(256) void k_cast_pad_colsum(const float* __restrict__ x, int rows, int C, int ldx,
+                                                         bf16* __restrict__ out, int ldo, int rpb, float* __restrict__ db) {
+  __shared__ float part[16][65];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = (blockIdx.x * 16 + cx) * 4;
+  const int r0 = blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+  float4 acc = make_float4(0.f, 0.f, 0.f, 0.f);
+  if (c < ldo) {
+    for (int r = r0 + ry; r < r1; r += 16) {
+      float4 v = make_float4(0.f, 0.f, 0.f, 0.f);
+      if (c < C) v = *reinterpret_cast<const float4*>(x + (size_t)r * ldx + c);
+      *reinterpret_cast<uint2*>(out + (size_t)r * ldo + c) = pack_bf16x4(v.x, v.y, v.z, v.w);
+      acc.x += v.x; acc.y += v.y; acc.z += v.z; acc.w += v.w;
+    }
+  }
+  part[ry][4 * cx] = acc.x; part[ry][4 * cx + 1] = acc.y; part[ry][4 * cx + 2] = acc.z; part[ry][4 * cx + 3] = acc.w;
+  __syncthreads();
+  if (threadIdx.x < 64) {
+    const int n = blockIdx.x * 64 + threadIdx.x;
+    if (n < C) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+      atomicAdd(db + n, t);
+    }
+  }
+}
+// GELU backward: dh = da gelu'(h) (bf16 [rows, ld], in place allowed), db[c] += sum_rows dh for c < N
+__global__ __launch_bounds__(256) void k_gelu_bwd_colsum(const bf16* __restrict__ h, const bf16* __restrict__ da,
+                                                         bf16* __restrict__ dh, int rows, int N, int ld, int rpb,
+                                                         float* __restrict__ db) {
+  __shared__ float part[16][129];
+  const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
+  const int c = (blockIdx.x * 16 + cx) * 8;
+  const int r0 = blockIdx.y * rpb, r1 = min(rows, r0 + rpb);
+  float acc[8];
+#pragma unroll
+  for (int j = 0; j < 8; ++j) acc[j] = 0.f;
+  if (c < ld) {
+    for (int r = r0 + ry; r < r1; r += 16) {
+      const size_t o = (size_t)r * ld + c;
+      const bf16x8 v = *reinterpret_cast<const bf16x8*>(h + o);
+      const bf16x8 g = *reinterpret_cast<const bf16x8*>(da + o);
+      bf16x8 w;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        w[j] = (bf16)((float)g[j] * gelu_grad((float)v[j]));
+        acc[j] += (float)w[j];
+      }
+      *reinterpret_cast<bf16x8*>(dh + o) = w;
+    }
+  }
+#pragma unroll
+  for (int j = 0; j < 8; ++j) part[ry][8 * cx + j] = acc[j];
+  __syncthreads();
+  if (threadIdx.x < 128) {
+    const int n = blockIdx.x * 128 + threadIdx.x;
+    if (n < N) {
+      float t = 0.f;
+#pragma unroll
+      for (int k = 0; k < 16; ++k) t += part[k][threadIdx.x];
+      atomicAdd(db + n, t);
+    }
+  }
+}
+
 // ---- LayerNorm backward: one wavefront per row (grid-stride), V float4 chunks per lane ----
 //   xhat = (x - mean) rstd, dxhat = dy g, dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) [+ dres]
 //   dg += sum_rows dy xhat, db += sum_rows dy
@@ -382,6 +451,30 @@ int launch_gelu_bwd(const bf16* h, const bf16* da, bf16* dh, size_t n, hipStream
   if (n % 8) return SWG_E_SHAPE;
   SwgProfScope ps(KID_BWD_ROWS, 0.0, 6.0 * (double)n, s);
   hipLaunchKernelGGL(k_gelu_bwd, dim3(gs_grid(n / 8)), dim3(256), 0, s, h, da, dh, n / 8);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+static inline int fused_rpb(int rows, int col_blocks) {  // >= ~2048 workgroups, at least 64 rows each
+  return max(64, cdiv(rows, max(1, 2048 / col_blocks)));
+}
+int launch_cast_pad_colsum(const float* x, int rows, int C, int ldx, bf16* out, int ldo, float* db, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (C % 4 || ldo % 4 || ldx % 4 || ldo < C) return SWG_E_SHAPE;
+  if (!x || !out || !db) return SWG_E_NULL;
+  const int cb = cdiv(ldo, 64), rpb = fused_rpb(rows, cb);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)rows * (4.0 * C + 2.0 * ldo), s);
+  hipLaunchKernelGGL(k_cast_pad_colsum, dim3(cb, cdiv(rows, rpb)), dim3(256), 0, s, x, rows, C, ldx, out, ldo, rpb, db);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, int rows, int N, int ld, float* db, hipStream_t s) {
+  if (rows <= 0) return 0;
+  if (ld % 8 || N > ld) return SWG_E_SHAPE;
+  if (!h || !da || !dh || !db) return SWG_E_NULL;
+  const int cb = cdiv(ld, 128), rpb = fused_rpb(rows, cb);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, 6.0 * (double)rows * ld, s);
+  hipLaunchKernelGGL(k_gelu_bwd_colsum, dim3(cb, cdiv(rows, rpb)), dim3(256), 0, s, h, da, dh, rows, N, ld, rpb, db);
   SWG_LAUNCH_CHECK();
   return 0;
 }

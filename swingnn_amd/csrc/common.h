@@ -200,6 +200,8 @@ int launch_colsum_f32(const float* src, int M, int N, int ld, float* out, hipStr
 int launch_colsum_bf16(const bf16* src, int M, int N, int ld, float* out, hipStream_t s);
 int launch_gelu_fwd(const bf16* h, bf16* a, size_t n, hipStream_t s);
 int launch_gelu_bwd(const bf16* h, const bf16* da, bf16* dh, size_t n, hipStream_t s);
+int launch_cast_pad_colsum(const float* x, int rows, int C, int ldx, bf16* out, int ldo, float* db, hipStream_t s);
+int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, int rows, int N, int ld, float* db, hipStream_t s);
 int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
                   float* dg, float* db, hipStream_t s);
 int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int cond_stride, int cond_off, int B, int L, int C,
