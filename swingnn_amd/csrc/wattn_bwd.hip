@@ -99,6 +99,15 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
   const int rem = a.hd - 8 * lg;
   const int troff = (4 * lg + q4) * LDT + 4 * p4;  // transposed-read address of this lane inside a 16-row tile
 
+  // dS summed over this workgroup's windows, in the phase-A register layout; scattered into the bias table once at the
+  // end (an LDS atomic per element and window kept every wave waiting on the LDS queue: 47 % of the wave cycles)
+  constexpr bool REGACC = NTL <= 3;  // 64-token windows keep the per-window LDS scatter: 64 more registers halve their occupancy
+  f32x4 dsacc[REGACC ? NTL : 1][REGACC ? NTL : 1];
+#pragma unroll
+  for (int i = 0; i < (REGACC ? NTL : 1); ++i)
+#pragma unroll
+    for (int j = 0; j < (REGACC ? NTL : 1); ++j) dsacc[i][j] = zero4;
+
   for (int u = blockIdx.y; u < a.B * nW; u += gridDim.y) {
     const int b = u / nW, wi = u - b * nW;
     const int wy = wi / nwx, wx = wi - wy * nwx;
@@ -142,7 +151,7 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
 #pragma unroll
     for (int it = 0; it < NTL; ++it) {
       f32x4 sv[NTL], dp[NTL];
-      int idx[NTL][4];
+      int pjs[REGACC ? 1 : NTL][4];
 #pragma unroll
       for (int jt = 0; jt < NTL; ++jt) {
         sv[jt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fk[jt], fq[it], zero4, 0, 0, 0);
@@ -158,11 +167,11 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
           const int id = pi - pjv[r];
+          if constexpr (!REGACC) pjs[jt][r] = pjv[r];
           float v = sv[jt][r] * a.scale + bias[id];
           if (SH && rjv[r] != myrid[it]) v += -100.0f;  // swin_gnn.py:226
           if (jt == NTL - 1 && 16 * jt + 4 * lg + r >= n) v = -3.0e38f;  // padding keys: only in the last tile
           sv[jt][r] = v;
-          idx[jt][r] = id;
           mx = fmaxf(mx, v);
         }
       }
@@ -199,7 +208,8 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
         for (int r = 0; r < 4; ++r) {
           const float ds = sv[jt][r] * (dp[jt][r] - delta);
           dp[jt][r] = ds;
-          atomicAdd(&dbias[idx[jt][r]], ds);
+          if constexpr (REGACC) dsacc[it][jt][r] += ds;
+          else atomicAdd(&dbias[pi - pjs[jt][r]], ds);
         }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -274,6 +284,16 @@ __global__ __launch_bounds__(64) void k_wattn_bwd(WbArgs a) {
         for (int c = 3 * a.C; c < a.lddq; c += 4) *reinterpret_cast<uint2*>(a.dqkv + tok[jt] * a.lddq + c) = make_uint2(0u, 0u);
     }
   }
+  if constexpr (REGACC)
+#pragma unroll
+  for (int it = 0; it < NTL; ++it)
+#pragma unroll
+    for (int jt = 0; jt < NTL; ++jt) {
+      const int4 pj = *reinterpret_cast<const int4*>(&pos[16 * jt + 4 * lg]);
+      const int pjv[4] = {pj.x, pj.y, pj.z, pj.w};
+#pragma unroll
+      for (int r = 0; r < 4; ++r) atomicAdd(&dbias[cpos + rpos[it] - pjv[r]], dsacc[it][jt][r]);
+    }
   __syncthreads();
   for (int t = lane; t < nb; t += 64) {
     const float v = dbias[t];
