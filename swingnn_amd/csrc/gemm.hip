@@ -304,8 +304,7 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_big(const bf16* __restrict__
 // no transposed copies.  A 32-token x 128-feature tile of each operand goes to LDS row-major (coalesced 16-byte
 // loads); the MFMA fragments, which need 8 consecutive TOKENS per lane, are gathered by ds_read_b64_tr_b16 (gfx950
 // transposing LDS read: 4 tokens x 16 features per 16-lane group, delivered feature-per-lane).  Rows are 288 bytes
-// apart (144 elements): the 16 lanes of a group then cover 32 distinct banks; the two groups of a 32-lane half sit 8
-// rows (= 0 mod 64 banks) apart, a 2-way conflict that costs what the NT kernel's ds_read_b128 costs.
+// apart (144 elements = 8 banks mod 64): the 32 lanes of one LDS pass read 8 consecutive rows, conflict-free.
 // Split over blockIdx.y along the tokens into fp32 partials like the NT form (k_splitk_reduce folds them).
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int TN_BT = 32;    // tokens per k-step
@@ -361,9 +360,11 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const bf16* __restrict__ P, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // transposed-read addresses: lane 4q+p of group lg supplies row (8 lg + 4 half + q), columns c0 + 4p .. 4p+3
+  // transposed-read addresses: lane 4q+p of group lg supplies row (4 lg + 16 half + q), columns c0 + 4p .. 4p+3: the
+  // contraction slots of a lane group are tokens {4 lg .. 4 lg + 3} and {16 + 4 lg ..} (any order works as long as both
+  // operands use it), so the 32 lanes of one LDS pass read 8 CONSECUTIVE rows = 8 x 32 B on distinct banks
   const int q4 = l15 >> 2, p4 = l15 & 3;
-  const int roff = (8 * lg + q4) * TN_LD + 4 * p4;  // half 0; half 1 adds 4 rows
+  const int roff = (4 * lg + q4) * TN_LD + 4 * p4;  // half 0; half 1 adds 16 rows
 
   typedef __attribute__((address_space(3))) bf16x4 lds_b4;
   int buf = 0;
@@ -381,9 +382,9 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const bf16* __restrict__ P, int
       const bf16* pa = &sP[buf][roff + wm * 64 + t * 16];
       const bf16* pb = &sQ[buf][roff + wn * 64 + t * 16];
       const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)pa);
-      const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pa + 4 * TN_LD));
+      const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pa + 16 * TN_LD));
       const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)pb);
-      const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pb + 4 * TN_LD));
+      const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pb + 16 * TN_LD));
       fa[t] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
       fb[t] = (bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
     }
