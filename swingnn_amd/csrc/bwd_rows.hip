@@ -257,29 +257,55 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
 
 // ---- conditioning backward: xc = silu(z), z = shift + x (1 + scale)  (swin_gnn.py:238-240, :571-574) ----
 // dx = dxc silu'(z) (1 + scale); dscale[b,c] += sum_t dz x; dshift[b,c] += sum_t dz.  grid (B, token chunks).
+// thread = (float4 column chunk, token phase): C / 4 chunks x (256 / chunks) phases, column partials folded through LDS
 __global__ __launch_bounds__(256) void k_cond_bwd(const float* __restrict__ x, const float* __restrict__ dxc,
                                                   const float* __restrict__ cond, int cond_stride, int cond_off, int C,
                                                   int L, int tpb, float* __restrict__ dx, float* __restrict__ dcond,
                                                   int dcond_stride) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
   const int b = blockIdx.x;
   const int t0 = blockIdx.y * tpb, t1 = min(L, t0 + tpb);
   const float* crow = cond + (size_t)b * cond_stride + cond_off;
   float* drow = dcond + (size_t)b * dcond_stride + cond_off;
-  for (int c = threadIdx.x; c < C; c += 256) {
-    const float sc = crow[c] + 1.f, sh = crow[C + c];
-    float asc = 0.f, ash = 0.f;
-    for (int t = t0; t < t1; ++t) {
-      const size_t o = ((size_t)b * L + t) * C + c;
-      const float xv = x[o];
-      const float z = sh + xv * sc;
-      const float sg = 1.0f / (1.0f + __expf(-z));
-      const float dz = dxc[o] * sg * (1.0f + z * (1.0f - sg));
-      if (dx) dx[o] = dz * sc;
-      asc += dz * xv;
-      ash += dz;
+  const int nch = C >> 2;
+  const int nph = max(1, 256 / nch);
+  for (int i = threadIdx.x; i < 2 * C; i += 256) red[i] = 0.f;
+  __syncthreads();
+  for (int cb = 0; cb < nch; cb += 256) {  // C > 1024 only: more than one pass over the chunks
+    const int ch = cb + (int)threadIdx.x % min(nch, 256), ph = (int)threadIdx.x / min(nch, 256);
+    if (ch < nch && ph < nph) {
+      const float4 scv = *reinterpret_cast<const float4*>(crow + 4 * ch);
+      const float4 shv = *reinterpret_cast<const float4*>(crow + C + 4 * ch);
+      const float sc[4] = {scv.x + 1.f, scv.y + 1.f, scv.z + 1.f, scv.w + 1.f}, sh[4] = {shv.x, shv.y, shv.z, shv.w};
+      float asc[4] = {0.f, 0.f, 0.f, 0.f}, ash[4] = {0.f, 0.f, 0.f, 0.f};
+      for (int t = t0 + ph; t < t1; t += nph) {
+        const size_t o = ((size_t)b * L + t) * C + 4 * ch;
+        const float4 xq = *reinterpret_cast<const float4*>(x + o);
+        const float4 dq = *reinterpret_cast<const float4*>(dxc + o);
+        const float xv[4] = {xq.x, xq.y, xq.z, xq.w}, dv[4] = {dq.x, dq.y, dq.z, dq.w};
+        float ov[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float z = sh[k] + xv[k] * sc[k];
+          const float sg = 1.0f / (1.0f + __expf(-z));
+          const float dz = dv[k] * sg * (1.0f + z * (1.0f - sg));
+          ov[k] = dz * sc[k];
+          asc[k] += dz * xv[k];
+          ash[k] += dz;
+        }
+        if (dx) *reinterpret_cast<float4*>(dx + o) = make_float4(ov[0], ov[1], ov[2], ov[3]);
+      }
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(&red[4 * ch + k], asc[k]);
+        atomicAdd(&red[C + 4 * ch + k], ash[k]);
+      }
     }
-    atomicAdd(drow + c, asc);
-    atomicAdd(drow + C + c, ash);
+  }
+  __syncthreads();
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(drow + c, red[c]);
+    atomicAdd(drow + C + c, red[C + c]);
   }
 }
 
@@ -508,8 +534,9 @@ int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int con
   const int chunks = max(1, min(L, cdiv(2048, B)));  // ~2048 workgroups
   const int tpb = cdiv(L, chunks);
   SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)B * L * C * 12.0, s);
-  hipLaunchKernelGGL(k_cond_bwd, dim3(B, cdiv(L, tpb)), dim3(256), 0, s, x, dxc, cond, cond_stride, cond_off, C, L, tpb, dx,
-                     dcond, dcond_stride);
+  if (C % 4) return SWG_E_SHAPE;
+  hipLaunchKernelGGL(k_cond_bwd, dim3(B, cdiv(L, tpb)), dim3(256), (size_t)2 * C * sizeof(float), s, x, dxc, cond, cond_stride,
+                     cond_off, C, L, tpb, dx, dcond, dcond_stride);
   SWG_LAUNCH_CHECK();
   return 0;
 }

@@ -301,23 +301,31 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_big(const bf16* __restrict__
 // ------------------------------------------------------------------------------------------------------------------
 // Weight-gradient GEMM on TOKEN-MAJOR operands:  out[Mo, No] += sum_t P[t, m] Q[t, n]   (dW = dY^T X)
 // P = dY (bf16 [rows, ldp]) and Q = X (bf16 [rows, ldq]) are read exactly as the forward / backward kernels wrote them:
-// no transposed copies.  A 32-token x 128-feature tile of each operand goes to LDS row-major (coalesced 16-byte
-// loads); the MFMA fragments, which need 8 consecutive TOKENS per lane, are gathered by ds_read_b64_tr_b16 (gfx950
-// transposing LDS read: 4 tokens x 16 features per 16-lane group, delivered feature-per-lane).  Rows are 288 bytes
-// apart (144 elements = 8 banks mod 64): the 32 lanes of one LDS pass read 8 consecutive rows, conflict-free.
-// Split over blockIdx.y along the tokens into fp32 partials like the NT form (k_splitk_reduce folds them).
+// no transposed copies.  A 32-token x 128-feature tile of each operand goes to LDS row-major; the MFMA fragments,
+// which need 8 consecutive TOKENS per lane, are gathered by ds_read_b64_tr_b16 (gfx950 transposing LDS read: 4 tokens
+// x 16 features per 16-lane group, delivered feature-per-lane).  The contraction slots of lane group g are tokens
+// {4 g .. 4 g + 3} and {16 + 4 g ..} (any order works as long as both operands use it), so the 32 lanes of one LDS pass
+// read 8 CONSECUTIVE rows.
+// The operand stream is the bound (SQ_WAIT_ANY 54 % of the wave cycles in a register-staged form with one tile in
+// flight per workgroup), so tiles go global -> LDS by LDS-DMA, TD_NBUF - 1 of them in flight behind a counted vmcnt.
+// One wave-instruction moves 4 rows x 256 B; LDS rows are 256 B with no padding, the bank spread comes from an XOR on
+// the 32-byte chunk-pair index applied on the GLOBAL side (lane (row, physical chunk) fetches logical chunk
+// pc ^ 2 (row & 7)): the 8 consecutive rows of one transposed-read pass land on 8 distinct chunk pairs.  Rows past the
+// slice end are fetched from a clamped (valid) row and the P fragment is zeroed instead.
+// 1-D grid over (token slice, tile): workgroup L runs on XCD L % 8, so slice = xcd + 8 (slot / tiles) keeps all tiles
+// of one token slice on ONE XCD, back to back (operands fetched from HBM once, the other tiles hit that L2).  Slices
+// write fp32 partials that k_splitk_reduce folds into `out`.
 // ------------------------------------------------------------------------------------------------------------------
 constexpr int TN_BT = 32;    // tokens per k-step
-constexpr int TN_LD = 144;   // LDS row stride in elements
+constexpr int TD_NBUF = 4;
+constexpr int TD_OP = TN_BT * 128;          // elements per operand tile
+constexpr int TD_STAGE = 2 * TD_OP;         // P tile then Q tile
 
-__global__ __launch_bounds__(256) void k_gemm_tn(const bf16* __restrict__ P, int ldp, const bf16* __restrict__ Q, int ldq,
-                                                 int rows, int Mo, int No, float* __restrict__ out, int tiles_n, int tiles,
-                                                 int nslices, int kslice, size_t out_slice, int accumulate) {
-  __shared__ __attribute__((aligned(16))) bf16 sP[2][TN_BT * TN_LD];
-  __shared__ __attribute__((aligned(16))) bf16 sQ[2][TN_BT * TN_LD];
-  // 1-D grid over (token slice, tile): workgroup L runs on XCD L % 8, so slice = xcd + 8 (slot / tiles) keeps all
-  // tiles of one token slice on ONE XCD, back to back: every operand byte is fetched from HBM once and the other
-  // tiles of the slice hit that XCD's L2
+__global__ __launch_bounds__(256, 2) void k_gemm_tn_dma(const bf16* __restrict__ P, int ldp, const bf16* __restrict__ Q,
+                                                        int ldq, int rows, int Mo, int No, float* __restrict__ out,
+                                                        int tiles_n, int tiles, int nslices, int kslice, size_t out_slice,
+                                                        int accumulate) {
+  __shared__ __attribute__((aligned(1024))) bf16 sm[TD_NBUF * TD_STAGE];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int sl = xcd + 8 * (slot / tiles);
   if (sl >= nslices) return;
@@ -330,28 +338,27 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const bf16* __restrict__ P, int
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lg = lane >> 4;
+  const int q4 = l15 >> 2, p4 = l15 & 3;
 
-  // staging: 32 rows x 16 chunks (16 B) per operand = 2 chunks per thread per operand
-  int srow[2], sch[2];
+  // DMA: wave-instruction j (0..7) of an operand tile covers rows 4 j .. 4 j + 3; this wave issues j = wave, wave + 4
+  const int dr = lane >> 4, dpc = lane & 15;
+  int drow[2], dcolp[2], dcolq[2];
+  unsigned ddst[2];
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
-    const int id = tid + i * 256;
-    srow[i] = id >> 4;
-    sch[i] = id & 15;
+    const int j = wave + 4 * i;
+    drow[i] = 4 * j + dr;
+    const int lc = dpc ^ (2 * (drow[i] & 7));
+    dcolp[i] = min(m0 + lc * 8, ldp - 8);
+    dcolq[i] = min(n0 + lc * 8, ldq - 8);
+    ddst[i] = j * 1024;
   }
-  bf16x8 rp[2], rq[2];
-  const bf16x8 zero8 = {(bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f, (bf16)0.f};
-#define TN_LOAD(T0)                                                                                     \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
-    const int t = (T0) + srow[i];                                                                        \
-    const int cm = m0 + sch[i] * 8, cn = n0 + sch[i] * 8;                                                \
-    rp[i] = (t < t_end && cm + 8 <= ldp) ? *reinterpret_cast<const bf16x8*>(P + (size_t)t * ldp + cm) : zero8; \
-    rq[i] = (t < t_end && cn + 8 <= ldq) ? *reinterpret_cast<const bf16x8*>(Q + (size_t)t * ldq + cn) : zero8; \
-  }
-#define TN_STORE(BUF)                                                                                   \
-  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                        \
-    *reinterpret_cast<bf16x8*>(&sP[BUF][srow[i] * TN_LD + sch[i] * 8]) = rp[i];                           \
-    *reinterpret_cast<bf16x8*>(&sQ[BUF][srow[i] * TN_LD + sch[i] * 8]) = rq[i];                           \
+  const unsigned sm_base = lds_addr(sm);
+#define TD_ISSUE(KT, BUF)                                                                                    \
+  _Pragma("unroll") for (int i = 0; i < 2; ++i) {                                                             \
+    const size_t t = (size_t)min(t_begin + (KT) * TN_BT + drow[i], rows - 1);                                 \
+    lds_dma16(P + t * ldp + dcolp[i], sm_base + (BUF) * (TD_STAGE * 2) + ddst[i]);                            \
+    lds_dma16(Q + t * ldq + dcolq[i], sm_base + (BUF) * (TD_STAGE * 2) + TD_OP * 2 + ddst[i]);                \
   }
 
   f32x4 acc[4][4];  // [mt][nt]
@@ -360,46 +367,64 @@ __global__ __launch_bounds__(256) void k_gemm_tn(const bf16* __restrict__ P, int
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  // transposed-read addresses: lane 4q+p of group lg supplies row (4 lg + 16 half + q), columns c0 + 4p .. 4p+3: the
-  // contraction slots of a lane group are tokens {4 lg .. 4 lg + 3} and {16 + 4 lg ..} (any order works as long as both
-  // operands use it), so the 32 lanes of one LDS pass read 8 CONSECUTIVE rows = 8 x 32 B on distinct banks
-  const int q4 = l15 >> 2, p4 = l15 & 3;
-  const int roff = (4 * lg + q4) * TN_LD + 4 * p4;  // half 0; half 1 adds 16 rows
-
-  typedef __attribute__((address_space(3))) bf16x4 lds_b4;
-  int buf = 0;
-  if (t_begin < t_end) {
-    TN_LOAD(t_begin);
-    TN_STORE(0);
+  // transposed-read element offsets inside an operand tile, per 16-column block t and half (rows 4 lg + q, 16 + ...)
+  int offa[4], offb[4];
+  {
+    const int r = 4 * lg + q4;  // (r & 7) is the same for r + 16
+    const int sw = 2 * (r & 7);
+#pragma unroll
+    for (int t = 0; t < 4; ++t) {
+      const int lca = 8 * wm + 2 * t + (p4 >> 1), lcb = 8 * wn + 2 * t + (p4 >> 1);
+      offa[t] = r * 128 + (lca ^ sw) * 8 + (p4 & 1) * 4;
+      offb[t] = r * 128 + (lcb ^ sw) * 8 + (p4 & 1) * 4;
+    }
   }
-  __syncthreads();
-  for (int t0 = t_begin; t0 < t_end; t0 += TN_BT) {
-    const bool more = t0 + TN_BT < t_end;
-    if (more) { TN_LOAD(t0 + TN_BT); }
+  typedef __attribute__((address_space(3))) bf16x4 lds_b4;
+
+  const int nk = (t_end - t_begin + TN_BT - 1) / TN_BT;
+#pragma unroll
+  for (int st = 0; st < TD_NBUF - 1; ++st)
+    if (st < nk) { TD_ISSUE(st, st); }
+  int buf = 0;
+  for (int kt = 0; kt < nk; ++kt) {
+    if (kt + 2 < nk) g2_wait_vm<8>();
+    else if (kt + 1 < nk) g2_wait_vm<4>();
+    else g2_wait_vm<0>();
+    __syncthreads();
+    if (kt + TD_NBUF - 1 < nk) {
+      const int nb = buf == 0 ? TD_NBUF - 1 : buf - 1;  // (kt + TD_NBUF - 1) % TD_NBUF
+      TD_ISSUE(kt + TD_NBUF - 1, nb);
+    }
+    const bf16* sp = sm + buf * TD_STAGE;
+    const bf16* sq = sp + TD_OP;
     bf16x8 fa[4], fb[4];
 #pragma unroll
     for (int t = 0; t < 4; ++t) {
-      const bf16* pa = &sP[buf][roff + wm * 64 + t * 16];
-      const bf16* pb = &sQ[buf][roff + wn * 64 + t * 16];
-      const bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)pa);
-      const bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pa + 16 * TN_LD));
-      const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)pb);
-      const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(pb + 16 * TN_LD));
+      bf16x4 a0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(sp + offa[t]));
+      bf16x4 a1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(sp + offa[t] + 16 * 128));
+      const bf16x4 b0 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(sq + offb[t]));
+      const bf16x4 b1 = __builtin_amdgcn_ds_read_tr16_b64_v4bf16((lds_b4*)(sq + offb[t] + 16 * 128));
       fa[t] = (bf16x8){a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
       fb[t] = (bf16x8){b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+    }
+    const int left = t_end - (t_begin + kt * TN_BT);  // valid tokens in this tile
+    if (left < TN_BT) {                               // slice tail: slot e of group lg is token 4 lg + e (+ 16)
+#pragma unroll
+      for (int t = 0; t < 4; ++t)
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const int tokn = 4 * lg + (e & 3) + (e >> 2) * 16;
+          if (tokn >= left) fa[t][e] = (bf16)0.f;
+        }
     }
 #pragma unroll
     for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
-    if (more) { TN_STORE(buf ^ 1); }
-    __syncthreads();
-    buf ^= 1;
+    buf = buf == TD_NBUF - 1 ? 0 : buf + 1;
   }
-#undef TN_LOAD
-#undef TN_STORE
-  // accumulator of tile (mt, nt): row i = 4 lg + r (feature m), column j = l15 (feature n)
+#undef TD_ISSUE
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -472,25 +497,25 @@ int launch_gemm_splitk(const bf16* A, int lda, const bf16* W, int ldw, int M, in
 int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int rows, int Mo, int No, float* out,
                           float* partial, size_t partial_floats, hipStream_t s) {
   if (rows <= 0 || Mo <= 0 || No <= 0) return 0;
-  if (ldp % 8 || ldq % 8 || No % 4) return SWG_E_SHAPE;
+  if (ldp % 8 || ldq % 8 || No % 4 || ldp < 8 || ldq < 8) return SWG_E_SHAPE;
   if (!P || !Q || !out) return SWG_E_NULL;
   const int tiles_m = cdiv(Mo, 128), tiles_n = cdiv(No, 128);
   const int tiles = tiles_m * tiles_n;
-  int S = min(min(cdiv(1024, tiles), max(rows / 256, 1)), 256);
+  int S = min(min(cdiv(512, tiles), max(rows / 256, 1)), 256);  // 2 workgroups per CU: one round
   while (S > 1 && (size_t)S * Mo * No > partial_floats) --S;
   int kslice = round_up(cdiv(rows, S), TN_BT);
   S = cdiv(rows, kslice);
   SwgProfScope ps(KID_GEMM, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
                                                            8.0 * Mo * (double)No, s);
   if (S <= 1) {
-    hipLaunchKernelGGL(k_gemm_tn, dim3(8 * tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, tiles, 1, kslice,
+    hipLaunchKernelGGL(k_gemm_tn_dma, dim3(8 * tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, tiles, 1, kslice,
                        (size_t)0, 1);
     SWG_LAUNCH_CHECK();
     return 0;
   }
   const size_t slice = (size_t)Mo * No;
   if (!partial || partial_floats < slice * S) return SWG_E_WORKSPACE;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n,
+  hipLaunchKernelGGL(k_gemm_tn_dma, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n,
                      tiles, S, kslice, slice, 0);
   SWG_LAUNCH_CHECK();
   const size_t n4 = slice / 4;
