@@ -13,6 +13,7 @@
 //  * blockIdx is remapped so that consecutive logical tiles (which share the activation row panel) land on
 //    the same XCD and hit its L2.
 #include "common.h"
+#include <cstdlib>
 
 namespace {
 
@@ -178,17 +179,22 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
 // counted vmcnt, one barrier per 32-deep k-step.  The DMA writes lane i to LDS chunk i, so the XOR swizzle of the
 // fragment reads is applied on the GLOBAL side: lane (row, physical chunk) fetches logical chunk pc ^ swz(row).
 // ------------------------------------------------------------------------------------------------------------------
-constexpr int G2_BM = 256, G2_BN = 128, G2_BK = 32, G2_NBUF = 3;
-constexpr int G2_STAGE = (G2_BM + G2_BN) * G2_BK;  // elements per stage: X tile then W tile
+constexpr int G2_BN = 128, G2_BK = 32;
 
 template <int N>
 __device__ __forceinline__ void g2_wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+// MT = MFMA token tiles per wave (8: 256-token block, 4: 128-token block); NB = LDS stages (NB - 1 tiles in flight)
+template <int MT, int NB>
 __global__ __launch_bounds__(256, 2) void k_gemm_nt_big(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W,
                                                         int ldw, int M, int N, int Kp, GemmEpi e, int tiles_n) {
-  __shared__ __attribute__((aligned(1024))) bf16 sm[G2_NBUF * G2_STAGE];
+  constexpr int G2_BM = 32 * MT;
+  constexpr int G2_STAGE = (G2_BM + G2_BN) * G2_BK;  // elements per stage: X tile then W tile
+  constexpr int XI = MT / 2;                          // X wave-instructions per wave and stage (W: 2)
+  constexpr int PER = XI + 2;                         // DMA instructions per wave and stage
+  __shared__ __attribute__((aligned(1024))) bf16 sm[NB * G2_STAGE];
   const int tile = xcd_remap(blockIdx.x, gridDim.x);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;
   const int m0 = tm * G2_BM, n0 = tn * G2_BN;
@@ -196,12 +202,12 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_big(const bf16* __restrict__
   const int wm = wave >> 1, wn = wave & 1;
   const int l15 = lane & 15, lg = lane >> 4;
 
-  // LDS-DMA sources: wave-instruction j of a stage covers tile rows 16 j .. 16 j + 15 (X: j < 16, W: j < 8)
+  // LDS-DMA sources: wave-instruction j of a stage covers tile rows 16 j .. 16 j + 15 (X: j < BM / 16, W: j < 8)
   const int lr = lane >> 2, pc = lane & 3;
-  const bf16* gsrc[6];
-  unsigned ldst[6];
+  const bf16* gsrc[PER];
+  unsigned ldst[PER];
 #pragma unroll
-  for (int i = 0; i < 4; ++i) {
+  for (int i = 0; i < XI; ++i) {
     const int j = wave + 4 * i, row = 16 * j + lr;
     gsrc[i] = A + (size_t)min(m0 + row, M - 1) * lda + Swz<32>::chunk(row, pc) * 8;
     ldst[i] = j * 1024;
@@ -209,24 +215,24 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_big(const bf16* __restrict__
 #pragma unroll
   for (int i = 0; i < 2; ++i) {
     const int j = wave + 4 * i, row = 16 * j + lr;
-    gsrc[4 + i] = W + (size_t)min(n0 + row, N - 1) * ldw + Swz<32>::chunk(row, pc) * 8;
-    ldst[4 + i] = G2_BM * G2_BK * 2 + j * 1024;
+    gsrc[XI + i] = W + (size_t)min(n0 + row, N - 1) * ldw + Swz<32>::chunk(row, pc) * 8;
+    ldst[XI + i] = G2_BM * G2_BK * 2 + j * 1024;
   }
   const unsigned sm_base = lds_addr(sm);
 #define G2_ISSUE(KT, BUF)                                                                          \
-  _Pragma("unroll") for (int i = 0; i < 6; ++i)                                                     \
+  _Pragma("unroll") for (int i = 0; i < PER; ++i)                                                   \
       lds_dma16(gsrc[i] + (size_t)(KT) * G2_BK, sm_base + (BUF) * (G2_STAGE * 2) + ldst[i]);
 
-  f32x4 acc[4][8];  // [nt][mt]
+  f32x4 acc[4][MT];  // [nt][mt]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 8; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
-  int fxo[8], fwo[4];
+  int fxo[MT], fwo[4];
 #pragma unroll
-  for (int t = 0; t < 8; ++t) {
-    const int r = wm * 128 + t * 16 + l15;
+  for (int t = 0; t < MT; ++t) {
+    const int r = wm * (16 * MT) + t * 16 + l15;
     fxo[t] = r * G2_BK + Swz<32>::chunk(r, lg) * 8;
   }
 #pragma unroll
@@ -236,34 +242,39 @@ __global__ __launch_bounds__(256, 2) void k_gemm_nt_big(const bf16* __restrict__
   }
 
   const int nk = Kp / G2_BK;
-  G2_ISSUE(0, 0);
-  if (nk > 1) { G2_ISSUE(1, 1); }
+#pragma unroll
+  for (int st = 0; st < NB - 1; ++st)
+    if (st < nk) { G2_ISSUE(st, st); }
   int buf = 0;
   for (int kt = 0; kt < nk; ++kt) {
-    if (kt + 1 < nk) g2_wait_vm<6>(); else g2_wait_vm<0>();
+    // stage kt must have landed; the up to NB - 2 younger stages stay in flight
+    const int younger = min(nk - 1 - kt, NB - 2);
+    if (younger >= 2) g2_wait_vm<2 * PER>();
+    else if (younger == 1) g2_wait_vm<PER>();
+    else g2_wait_vm<0>();
     __syncthreads();
-    if (kt + 2 < nk) {
-      const int nb = buf >= 1 ? buf - 1 : 2;  // (kt + 2) % 3
-      G2_ISSUE(kt + 2, nb);
+    if (kt + NB - 1 < nk) {
+      const int nb = buf == 0 ? NB - 1 : buf - 1;  // (kt + NB - 1) % NB
+      G2_ISSUE(kt + NB - 1, nb);
     }
     const bf16* st = sm + buf * G2_STAGE;
-    bf16x8 fw[4], fx[8];
+    bf16x8 fw[4], fx[MT];
 #pragma unroll
     for (int t = 0; t < 4; ++t) fw[t] = *reinterpret_cast<const bf16x8*>(st + fwo[t]);
 #pragma unroll
-    for (int t = 0; t < 8; ++t) fx[t] = *reinterpret_cast<const bf16x8*>(st + fxo[t]);
+    for (int t = 0; t < MT; ++t) fx[t] = *reinterpret_cast<const bf16x8*>(st + fxo[t]);
 #pragma unroll
-    for (int mt = 0; mt < 8; ++mt)
+    for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[nt][mt], 0, 0, 0);
-    buf = buf == 2 ? 0 : buf + 1;
+    buf = buf == NB - 1 ? 0 : buf + 1;
   }
 #undef G2_ISSUE
 
 #pragma unroll
-  for (int mt = 0; mt < 8; ++mt) {
-    const int m = m0 + wm * 128 + mt * 16 + l15;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wm * (16 * MT) + mt * 16 + l15;
     if (m >= M) continue;
     const float* crow = e.cond ? e.cond + (size_t)(m / e.cond_L) * e.cond_stride + e.cond_off : nullptr;
 #pragma unroll
@@ -540,11 +551,19 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   // BK = 32 halves the LDS footprint (4 workgroups per CU instead of 2): with many row panels in flight the extra
   // residency hides the short-K prologue / epilogue better than the longer k-step amortises its barrier (measured
   // per shape, scripts/bench_gemm.py: +5..25 % for M >= 32k, -3..10 % for M = 8k)
-  const int big_wg = cdiv(M, G2_BM) * tiles_n;
-  // measured per shape (scripts/bench_gemm.py, B = 112): the large form wins for wide outputs and for very long token
-  // panels; short-K fp32 + residual shapes (epilogue-bound) keep the small form's higher workgroup residency
-  if (big_wg >= 384 && (ee.n_store >= 1024 || M >= 131072)) {
-    hipLaunchKernelGGL(k_gemm_nt_big, dim3(big_wg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n);
+  // form: 0 = by shape (below), 1 = register-staged 128 x 128, 3 = LDS-DMA 256 x 128 (SWG_GEMM_FORM, read once: a
+  // tuning knob for scripts/bench_gemm.py, not an API).  An LDS-DMA 128 x 128 form (4 stages) was measured too: equal
+  // or up to 10 % slower than the register-staged one on every shape of the network, so it is not built.
+  static const int forced = [] { const char* v = getenv("SWG_GEMM_FORM"); return v ? atoi(v) : 0; }();
+  const int big_wg = cdiv(M, 256) * tiles_n;
+  int form = forced;
+  if (form == 0) {
+    // measured per shape (scripts/bench_gemm.py, B = 112): the large form wins for wide outputs and for very long token
+    // panels; short-K fp32 + residual shapes (epilogue-bound) keep the small form's higher workgroup residency
+    form = (big_wg >= 384 && (ee.n_store >= 1024 || M >= 131072 || (ee.n_store >= 768 && M >= 65536))) ? 3 : 1;
+  }
+  if (form == 3) {
+    hipLaunchKernelGGL((k_gemm_nt_big<8, 3>), dim3(big_wg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n);
     SWG_LAUNCH_CHECK();
     return 0;
   }
