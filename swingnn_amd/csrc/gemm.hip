@@ -332,7 +332,7 @@ constexpr int TD_NBUF = 4;
 constexpr int TD_OP = TN_BT * 128;          // elements per operand tile
 constexpr int TD_STAGE = 2 * TD_OP;         // P tile then Q tile
 
-__global__ __launch_bounds__(256, 2) void k_gemm_tn_dma(const bf16* __restrict__ P, int ldp, const bf16* __restrict__ Q,
+__global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ P, int ldp, const bf16* __restrict__ Q,
                                                         int ldq, int rows, int Mo, int No, float* __restrict__ out,
                                                         int tiles_n, int tiles, int nslices, int kslice, size_t out_slice,
                                                         int accumulate) {
@@ -519,14 +519,14 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
   SwgProfScope ps(KID_GEMM, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
                                                            8.0 * Mo * (double)No, s);
   if (S <= 1) {
-    hipLaunchKernelGGL(k_gemm_tn_dma, dim3(8 * tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, tiles, 1, kslice,
+    hipLaunchKernelGGL(k_gemm_tn, dim3(8 * tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, tiles, 1, kslice,
                        (size_t)0, 1);
     SWG_LAUNCH_CHECK();
     return 0;
   }
   const size_t slice = (size_t)Mo * No;
   if (!partial || partial_floats < slice * S) return SWG_E_WORKSPACE;
-  hipLaunchKernelGGL(k_gemm_tn_dma, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n,
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n,
                      tiles, S, kslice, slice, 0);
   SWG_LAUNCH_CHECK();
   const size_t n4 = slice / 4;
