@@ -278,6 +278,15 @@ typedef struct swg_ends_train {
 } swg_ends_train;
 
 size_t swg_train_workspace_bytes(const swg_net* net, int32_t B);
+
+/* Weight gradient of a token-wise nn.Linear on bf16 operands (autograd of qkv / proj / fc1 / fc2 / reduction /
+ * pre_linear / post_linear, model/swin_gnn/swin_gnn.py:19-25, :113, :137, :334, :385-403; the op behind every dW of
+ * the train step, runner/trainer/trainer.py:130):  dw[N,K] (dense fp32) += dy[rows, :N]^T x[rows, :K].
+ * dy bf16 [rows, ldy], x bf16 [rows, ldx] TOKEN-MAJOR as the forward wrote them (ldy, ldx multiples of 8, >= N, K;
+ * K a multiple of 4).  Workspace >= swg_linear_wgrad_workspace_bytes(N, K) (fp32 partials of the token slices). */
+size_t swg_linear_wgrad_workspace_bytes(int32_t N, int32_t K);
+int swg_linear_wgrad_bf16(int32_t rows, int32_t N, int32_t K, const void* dy, int32_t ldy, const void* x, int32_t ldx,
+                          float* dw, void* ws, size_t ws_bytes, void* stream);
 /* (c_skip, c_out, c_in, c_noise) rows of runner/objectives/edm.py:122-126 for `labels` = sigmas (mode 1) or
  * (0, 1, 1, label) (mode 0): coef [B,4], c_noise [B]. */
 int swg_edm_coef(int32_t B, const float* labels, int32_t labels_uniform, int32_t mode, float* coef, float* c_noise,

@@ -112,6 +112,8 @@ SYMBOLS = {
     "swg_patch_expand_fwd": (C.c_int, [C.POINTER(SwgBreakup), _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
     "swg_readout_sym_precond_fwd": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "swg_linear_bf16": (C.c_int, [_i32, _i32, _i32, _fp, _i32, _fp, _fp, _i32, _fp, _fp, _fp, _i32, _fp]),
+    "swg_linear_wgrad_workspace_bytes": (_sz, [_i32, _i32]),
+    "swg_linear_wgrad_bf16": (C.c_int, [_i32, _i32, _i32, _fp, _i32, _fp, _i32, _fp, _fp, _sz, _fp]),
     "swg_heun_churn": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _f, _fp, _fp]),
     "swg_heun_euler": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _f, _f, _i32, _fp, _fp, _fp]),
     "swg_heun_correct": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp]),

@@ -528,4 +528,19 @@ int swg_nodeadj_readout_bwd(const swg_net* net, const swg_nodeadj* na, const swg
   return na_readout_bwd_impl(net, na, tr, B, tok, node_flags, coef, d_adj, d_node, dtok, cv, (hipStream_t)stream);
 }
 
+size_t swg_linear_wgrad_workspace_bytes(int32_t N, int32_t K) {
+  if (N <= 0 || K <= 0) return 0;
+  return gemm_splitk_ws_floats(N, K) * sizeof(float) + 256;
+}
+int swg_linear_wgrad_bf16(int32_t rows, int32_t N, int32_t K, const void* dy, int32_t ldy, const void* x, int32_t ldx,
+                          float* dw, void* ws, size_t ws_bytes, void* stream) {
+  if (!dy || !x || !dw) return SWG_E_NULL;
+  if (rows <= 0 || N <= 0 || K <= 0 || ldy < N || ldx < K) return SWG_E_SHAPE;
+  Carver cv(ws, ws_bytes);
+  const size_t pf = gemm_splitk_ws_floats(N, K);
+  float* partial = cv.take<float>(pf);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  return launch_gemm_tn_splitk((const bf16*)dy, ldy, (const bf16*)x, ldx, rows, N, K, dw, partial, pf, (hipStream_t)stream);
+}
+
 }  // extern "C"
