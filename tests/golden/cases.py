@@ -72,6 +72,9 @@ SAMPLER_CASES = {
 TRAIN_CASES = [("com96", "stress", 0, True), ("com96", "init", 1, False), ("ego60", "stress", 1, True),
                ("grid192", "stress", 0, True), ("ego60_nosc", "stress", 0, False), ("grid192", "init", 1, True),
                ("ego60", "init", 0, True)]
+# GPU-only extra (no stored fingerprint: gradients are checked against autograd through the oracle, whose forward for
+# this geometry is pinned by the 'net/dd256/*' goldens): 8 x 8 windows WITH shift, the 64-token attention-backward path
+TRAIN_CASES_GPU_EXTRA = [("dd256", "init", 0, True)]
 
 
 # G10: NodeAdjSwinGNN / NodeAdjPrecond / NodeAdjEDMSampler (molecule path).  in_chans = 2*Cn + Ca before the

@@ -19,12 +19,12 @@ import torch
 
 from oracle import swingnn_ref as O
 from tests import helpers as H
-from tests.golden.cases import NET_CASES, TRAIN_CASES
+from tests.golden.cases import NET_CASES, TRAIN_CASES, TRAIN_CASES_GPU_EXTRA
 
 pytestmark = pytest.mark.gpu
 DEV = "cuda:0"
 
-@pytest.mark.parametrize("name,regime,si,coin", TRAIN_CASES)
+@pytest.mark.parametrize("name,regime,si,coin", TRAIN_CASES + TRAIN_CASES_GPU_EXTRA)
 def test_train_step_gradients(golden_meta, name, regime, si, coin, monkeypatch):
     assert torch.cuda.is_available(), "GPU tests need an MI355X"
     import swingnn_amd as S
