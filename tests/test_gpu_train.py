@@ -160,3 +160,46 @@ def test_derived_operand_refresh_equals_rebuild(golden_meta, golden_nodeadj, kin
     for k in tcache.wt:
         assert torch.equal(tcache.wt[k], tfresh.wt[k]), k
     assert torch.equal(tcache.pe_wb, tfresh.pe_wb)
+
+
+@pytest.mark.parametrize("win,img", [(5, 80), (7, 112), (3, 48)])
+def test_train_step_gradients_odd_windows(win, img):
+    """Window sides the named configs do not use (25 / 49 / 9 tokens per window: 2, 4 and 1 MFMA token tiles with a
+    ragged last tile, with shift): loss and gradients against autograd through the oracle.  No stored fingerprint --
+    the oracle's window / shift / mask arithmetic is the code the 'block/*' and 'net/*' goldens pin."""
+    import swingnn_amd as S
+    from tests.test_gpu_parity import load
+    from tests.golden.cases import _cfg
+    from oracle import filler
+    cfg = _cfg(img, 4, 96, [2, 2], win)
+    net = S.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=cfg["in_chans"],
+                    embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
+                    window_size=cfg["window_size"], mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                    drop_path_rate=0.0, self_condition=True)
+    pre = S.Precond("edm", net, True)
+    meta = {k: [list(v.shape), str(v.dtype)] for k, v in pre.state_dict().items()}
+    sd = H.net_state(meta, 77 + win, "init")
+    pre = load(pre, sd).train()
+    case = dict(cfg=cfg, B=2, n_lo=img // 2, n_hi=img - 3, sigmas=[1.0], seed=70 + win)
+    flags, x, sig, w, clean = H.train_case_inputs(case, 0)
+    ref_loss, ref = H.oracle_grads(sd, cfg, x, flags, sig, w, clean, True)
+    loss_fn = S.RainbowLoss(regression_loss_weight=1.0, flag_reweight=False, objective="edm")
+    saved = np.random.rand
+    np.random.rand = lambda: 0.25
+    try:
+        with torch.enable_grad():
+            D = pre(x=x.to(DEV), node_flags=flags.to(DEV), sigmas=sig.to(DEV))
+            loss = loss_fn(net_pred=D, net_target=clean.to(DEV), net_cond=sig.to(DEV), adjs_perturbed=x.to(DEV),
+                           adjs_gt=clean.to(DEV), node_flags=flags.to(DEV), loss_weight=w.to(DEV), reduction='none')
+            loss.mean().backward()
+    finally:
+        np.random.rand = saved
+    assert torch.allclose(loss.detach().cpu(), ref_loss, rtol=1e-3, atol=1e-6)
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in ref.values())))
+    bad = []
+    for k, p in pre.named_parameters():
+        g, r = p.grad.detach().float().cpu(), ref[k]
+        rel = float((g - r).norm()) / max(float(r.norm()), 1e-3 * total)
+        if rel > 3e-2:
+            bad.append((k, rel))
+    assert not bad, bad
