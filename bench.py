@@ -217,7 +217,7 @@ def main():
         }
         if reuse is not None:
             result["pass_reuse"] = reuse
-        if not args.no_cpu_baseline:
+        if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             result["cpu_baseline"] = cpu_baseline(cfg, model.state_dict())
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
     if world > 1:
