@@ -8,27 +8,28 @@ import torch
 
 def load_model(ckp_data, model, weight_keyword):
     """utils/sampling_utils.py:87-113: strict load of ``ckp_data[weight_keyword]`` into ``model``; a ``module.`` prefix
-    on either side (DDP / DataParallel checkpoints, runner/trainer/trainer_utils.py:164-181) is reconciled by sorted
-    key order exactly as the reference does."""
-    assert weight_keyword in ckp_data
-    cur_keys = sorted(list(model.state_dict().keys()))
-    ckp_keys = sorted(list(ckp_data[weight_keyword].keys()))
-    if set(cur_keys) == set(cur_keys) & set(ckp_keys):
-        model.load_state_dict(ckp_data[weight_keyword], strict=True)
-        return model
-    to_load = {}
-    for cur_key, ckp_key in zip(cur_keys, ckp_keys):
-        if cur_key == ckp_key:
-            pass
-        elif cur_key.startswith('module.') and not ckp_key.startswith('module.'):
-            assert cur_key == 'module.' + ckp_key
-        elif ckp_key.startswith('module.') and not cur_key.startswith('module.'):
-            assert 'module.' + cur_key == ckp_key
-        else:
-            raise NotImplementedError
-        to_load[cur_key] = ckp_data[weight_keyword][ckp_key]
-    assert set(cur_keys) == set(to_load.keys())
-    model.load_state_dict(to_load, strict=True)
+    on either side (DDP / DataParallel checkpoints, runner/trainer/trainer_utils.py:164-181) is reconciled.  Same
+    contract as the reference (strict load, KeyError-free for the two wrappings), written on canonical names: both key
+    sets are reduced to their un-prefixed form, compared, and the checkpoint tensors are re-keyed to the model's
+    spelling."""
+    if weight_keyword not in ckp_data:
+        # the reference asserts here (sampling_utils.py:92); same exception type for callers that catch it
+        raise AssertionError(f"checkpoint has no entry {weight_keyword!r}; entries: {sorted(ckp_data.keys())}")
+    weights = ckp_data[weight_keyword]
+    prefix = "module."
+
+    def canonical(name):
+        return name[len(prefix):] if name.startswith(prefix) else name
+
+    by_canonical = {canonical(k): v for k, v in weights.items()}
+    if len(by_canonical) != len(weights):
+        raise ValueError("checkpoint holds both a wrapped and an unwrapped copy of some tensor")
+    wanted = list(model.state_dict().keys())
+    missing = [k for k in wanted if canonical(k) not in by_canonical]
+    extra = set(by_canonical) - {canonical(k) for k in wanted}
+    if missing or extra:
+        raise RuntimeError(f"state-dict mismatch: missing {missing[:5]}, unexpected {sorted(extra)[:5]}")
+    model.load_state_dict({k: by_canonical[canonical(k)] for k in wanted}, strict=True)
     return model
 
 

@@ -64,7 +64,8 @@ class FusedAdamEMA(torch.optim.Optimizer):
         self.m = torch.zeros(off, dtype=torch.float32, device=dev)
         self.v = torch.zeros(off, dtype=torch.float32, device=dev)
         self.ema = torch.zeros((max(len(self.ema_betas), 1), off), dtype=torch.float32, device=dev)
-        self._p_ptrs = torch.tensor([p.data_ptr() for p in self.params], dtype=torch.int64, device=dev)
+        self._p_key = tuple(p.data_ptr() for p in self.params)
+        self._p_ptrs = torch.tensor(self._p_key, dtype=torch.int64, device=dev)
         self._g_ptrs = torch.zeros(len(self.params), dtype=torch.int64, device=dev)
         self._g_key = None
         self._sqnorm = torch.zeros(1, dtype=torch.float32, device=dev)
@@ -83,6 +84,54 @@ class FusedAdamEMA(torch.optim.Optimizer):
     def ema_parameters(self, k):
         """Views of EMA copy k (sorted by beta) shaped like the parameters, in parameter order."""
         return [self.ema[k, o:o + p.numel()].view(p.shape) for o, p in zip(self._offs, self.params)]
+
+    def ema_state_dict(self, k, model):
+        """EMA copy k (sorted by beta) as a state dict of ``model`` -- what the reference checkpoints under
+        ``model_ema_beta_{beta:.4f}`` (``ema.ema_model.state_dict()``, runner/trainer/trainer_utils.py:176-179):
+        parameters come from the EMA buffer, registered buffers (relative_position_index, attn_mask) are copied from
+        the model.  Tensors are clones, safe to ``torch.save``."""
+        by_id = {id(p): i for i, p in enumerate(self.params)}
+        ema = self.ema_parameters(k)
+        out = {}
+        named = dict(model.named_parameters(remove_duplicate=False))
+        for name, t in model.state_dict().items():
+            p = named.get(name)
+            if p is not None and id(p) in by_id:
+                out[name] = ema[by_id[id(p)]].detach().clone()
+            else:
+                out[name] = t.detach().clone()
+        return out
+
+    def ema_checkpoint_entries(self, model):
+        """``{'model_ema_beta_{beta:.4f}': state_dict}`` for every EMA copy: the entries get_ckpt_data adds
+        (trainer_utils.py:176-179) and eval.py:14-36 selects with ``--use_ema``."""
+        return {"model_ema_beta_{:.4f}".format(b): self.ema_state_dict(k, model) for k, b in enumerate(self.ema_betas)}
+
+    # ---- checkpoint / resume of the optimizer itself (moments, step counters, EMA copies) ----
+    def state_dict(self):
+        sd = super().state_dict()  # param_groups (lr, betas, ...); per-parameter state is kept flat, below
+        sd["fused"] = {
+            "m": self.m.detach().clone(), "v": self.v.detach().clone(), "ema": self.ema.detach().clone(),
+            "step_count": self.step_count, "ema_updates": self.ema_updates, "ema_betas": list(self.ema_betas),
+            "numel": [p.numel() for p in self.params],
+        }
+        return sd
+
+    def load_state_dict(self, state_dict):
+        state_dict = dict(state_dict)
+        fused = state_dict.pop("fused", None)
+        if fused is None:
+            raise KeyError("FusedAdamEMA.load_state_dict: no 'fused' entry (not a FusedAdamEMA checkpoint)")
+        if list(fused["numel"]) != [p.numel() for p in self.params]:
+            raise ValueError("FusedAdamEMA.load_state_dict: parameter list differs from the checkpoint's")
+        if [float(b) for b in fused["ema_betas"]] != list(self.ema_betas):
+            raise ValueError("FusedAdamEMA.load_state_dict: EMA betas differ from the checkpoint's")
+        super().load_state_dict(state_dict)
+        self.m.copy_(fused["m"])
+        self.v.copy_(fused["v"])
+        self.ema.copy_(fused["ema"])
+        self.step_count = int(fused["step_count"])
+        self.ema_updates = int(fused["ema_updates"])
 
     def grad_norm(self):
         """Total L2 gradient norm measured by the last step() (before clipping), as a 0-dim device tensor."""
@@ -104,6 +153,10 @@ class FusedAdamEMA(torch.optim.Optimizer):
         if key != self._g_key:  # zero_grad(set_to_none=True) gives new gradient tensors every step
             self._g_ptrs.copy_(torch.tensor(key, dtype=torch.int64), non_blocking=False)
             self._g_key = key
+        pkey = tuple(p.data_ptr() for p in self.params)
+        if pkey != self._p_key:  # parameter storage moved (model.to(), p.data = ..., load_state_dict(assign=True))
+            self._p_ptrs.copy_(torch.tensor(pkey, dtype=torch.int64), non_blocking=False)
+            self._p_key = pkey
         grp = self.param_groups[0]
         st = stream_ptr()
         sq = None

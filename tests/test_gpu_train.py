@@ -123,6 +123,69 @@ def test_train_steps_reduce_loss(golden_meta, monkeypatch):
     assert losses[-1] < losses[0], losses
 
 
+def test_optimizer_checkpoint_round_trip(golden_meta, monkeypatch, tmp_path):
+    """train -> checkpoint in the reference's format (runner/trainer/trainer_utils.py:164-181: 'model' +
+    'model_ema_beta_{beta:.4f}') -> io.load_model into a fresh Precond (eval.py:46-51), and resume of the optimizer
+    itself: a resumed FusedAdamEMA continues like the uninterrupted one (restored state bit-identical; the next step
+    equal up to the summation order of the backward's float atomics)."""
+    import swingnn_amd as S
+    from swingnn_amd import io
+    from tests.test_gpu_parity import build_precond
+    c = NET_CASES["com96"]
+    flags, x, sig, w, clean = (t.to(DEV) for t in H.train_case_inputs(c, 1))
+    loss_fn = S.RainbowLoss(1.0, False, "edm")
+    monkeypatch.setattr(np.random, "rand", lambda: 0.75)
+    betas = (0.9, 0.99)
+
+    def one_step(pre, opt):
+        with torch.enable_grad():
+            opt.zero_grad(set_to_none=True)
+            D = pre(x=x, node_flags=flags, sigmas=sig)
+            loss_fn(D, clean, sig, x, clean, flags, loss_weight=w, reduction='none').mean().backward()
+            opt.step()
+
+    pre = build_precond(S, "com96", golden_meta, "init").train()
+    opt = S.FusedAdamEMA(pre.parameters(), lr=1e-3, max_norm=10.0, ema_betas=betas)
+    for _ in range(3):
+        one_step(pre, opt)
+    ckpt = {"model": pre.state_dict(), "epoch": 3, **opt.ema_checkpoint_entries(pre), "optimizer": opt.state_dict()}
+    assert {"model_ema_beta_0.9000", "model_ema_beta_0.9900"} <= set(ckpt)
+    path = tmp_path / "ckpt.pth"
+    torch.save(ckpt, path)
+    back = torch.load(path, map_location="cpu", weights_only=True)
+
+    # the EMA entry has the model's exact key set, EMA values for parameters and the model's buffers
+    ema_sd = back["model_ema_beta_0.9900"]
+    assert list(ema_sd.keys()) == list(pre.state_dict().keys())
+    fresh = build_precond(S, "com96", golden_meta, "stress")
+    io.load_model(back, fresh, "model_ema_beta_0.9900")
+    named = dict(pre.named_parameters())
+    for (k, v), e in zip(named.items(), opt.ema_parameters(1)):
+        assert torch.equal(fresh.state_dict()[k].cpu(), e.cpu()), k
+    assert any(not torch.equal(fresh.state_dict()[k].cpu(), v.detach().cpu()) for k, v in named.items())
+    for k, v in pre.state_dict().items():
+        if k not in named:
+            assert torch.equal(fresh.state_dict()[k].cpu(), v.cpu()), k
+    out = fresh.eval()(x, flags, sig)   # the loaded EMA weights run through the HIP path
+    assert torch.isfinite(out).all()
+
+    # resume: model + optimizer from the checkpoint continue exactly like the original
+    pre2 = build_precond(S, "com96", golden_meta, "stress").train()
+    io.load_model(back, pre2, "model")
+    opt2 = S.FusedAdamEMA(pre2.parameters(), lr=5e-2, max_norm=10.0, ema_betas=betas)
+    opt2.load_state_dict(back["optimizer"])
+    assert opt2.param_groups[0]["lr"] == 1e-3 and opt2.step_count == 3 and opt2.ema_updates == 3
+    assert torch.equal(opt.ema, opt2.ema) and torch.equal(opt.m, opt2.m) and torch.equal(opt.v, opt2.v)
+    for (k, a), b in zip(pre.named_parameters(), pre2.parameters()):
+        assert torch.equal(a, b), k
+    one_step(pre, opt)
+    one_step(pre2, opt2)
+    for (k, a), b in zip(pre.named_parameters(), pre2.parameters()):
+        assert torch.allclose(a, b, rtol=1e-4, atol=2e-5), (k, float((a - b).abs().max()))   # lr 1e-3: one Adam step moves <= 1e-3
+    assert torch.allclose(opt.ema, opt2.ema, rtol=1e-4, atol=2e-5)
+    assert torch.allclose(opt.m, opt2.m, rtol=1e-3, atol=1e-6)
+
+
 @pytest.mark.parametrize("kind", ["swingnn", "nodeadj"])
 def test_derived_operand_refresh_equals_rebuild(golden_meta, golden_nodeadj, kind):
     """After the parameters change in place (optimizer step), engine.get_cache refreshes every derived operand with
