@@ -67,6 +67,14 @@ SAMPLER_CASES = {
     "grid192_4": dict(net="grid192", regime="init", steps=4, B=1, n_lo=100, n_hi=181, sanity=False, seed=64),
 }
 
+# Long trajectories (tests/golden/make_golden_sampler_long.py -> golden_sampler_long.npz): bf16 drift over all 256 Heun
+# steps on the grid geometry (shifted 6x6 windows live) and on community-small dim-96.  GPU tests only read them; the
+# CPU oracle test replays the cheap one.
+SAMPLER_LONG_CASES = {
+    "grid192_256": dict(net="grid192", regime="init", steps=256, B=1, n_lo=100, n_hi=181, sanity=False, seed=65),
+    "com96_256": dict(net="com96", regime="init", steps=256, B=3, n_lo=12, n_hi=20, sanity=False, seed=66),
+}
+
 # G9: train step (loss [B] + every parameter gradient) of RainbowLoss(Precond(SwinGNN)(x, flags, sigmas), sign(x)).mean()
 # (network case, weight regime, sigma index, outcome of the self-conditioning coin)
 TRAIN_CASES = [("com96", "stress", 0, True), ("com96", "init", 1, False), ("ego60", "stress", 1, True),

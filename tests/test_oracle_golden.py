@@ -118,6 +118,26 @@ def test_edm_sampler(golden, golden_meta, name):
         assert H.max_abs(out, gt) < 1e-5
 
 
+def test_edm_sampler_long_com96(golden_meta):
+    """The oracle replays the reference's full 256-step community-small dim-96 sample (golden_sampler_long.npz; the
+    grid192 trajectory of that file costs a minute of CPU and is replayed by the GPU test only)."""
+    import os
+    from tests.golden.cases import SAMPLER_LONG_CASES
+    name = "com96_256"
+    c = SAMPLER_LONG_CASES[name]
+    cfg = NET_CASES[c["net"]]["cfg"]
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_sampler_long.npz"), allow_pickle=False) as z:
+        ref, thr_ref = torch.from_numpy(z[f"sampler/{name}/final"]), torch.from_numpy(z[f"sampler/{name}/thresholded"])
+    sd = H.net_state(golden_meta[f"keys/{c['net']}"], c["seed"], c["regime"])
+    flags = filler.node_flags("flags", c["B"], cfg["img_size"], c["n_lo"], c["n_hi"], c["seed"])
+    torch.manual_seed(c["seed"])
+    np.random.seed(c["seed"])
+    out = O.edm_sample(lambda x, fl, sig, sc: O.precond_forward(sd, cfg, x, fl, sig, np.random.rand() < 0.5), flags,
+                       num_steps=c["steps"], self_condition=True)
+    close(out, ref, 2e-4)
+    assert float((O.threshold_adj(out, flags) == thr_ref).float().mean()) >= 0.999
+
+
 def test_objective_and_loss(golden):
     B, N = 6, 24
     flags = filler.node_flags("flags", B, N, 5, 20, 3)
