@@ -235,6 +235,16 @@ int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, c
                  float* scratch2B, void* stream);
 
 
+/* swg_edm_loss without the scratch2B argument.  NO COUNTERPART IN THE REFERENCE: it exists for callers that cannot
+ * allocate device memory (code under HIP graph capture, tight serving loops, harnesses that forbid hipMalloc).  Same
+ * kernels and results as swg_edm_loss; the 2*B partial sums live in a 512-KiB file-scope device array of the library
+ * (one copy per GPU, held until the process ends).  B <= 65536, else SWG_E_WORKSPACE.  Calls no hipMalloc / hipFree.
+ * The current device must be the stream's device.  All calls on one GPU share the array: calls that overlap on one
+ * GPU (different streams / threads) race; stream-ordered calls are safe (nothing needs to start at zero). */
+int swg_edm_loss_noalloc(int32_t B, int32_t N, const float* pred, const float* target, const float* node_flags,
+                         const float* weights, float regression_loss_weight, int32_t reduction_mean, float* loss,
+                         void* stream);
+
 /* ---- training step: backward passes of the op-level entry points ------------------------ *
  * The reference has no explicit backward code: `loss.backward()` (runner/trainer/trainer.py:135) differentiates the
  * module forwards cited above with autograd.  Each *_bwd entry point below is the derivative of the *_fwd entry point

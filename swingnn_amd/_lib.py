@@ -127,6 +127,7 @@ SYMBOLS = {
     "swg_heun_nodes_correct": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _f, _f, _fp, _fp]),
     "swg_edm_objective": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "swg_edm_loss": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _f, _i32, _fp, _fp, _fp]),
+    "swg_edm_loss_noalloc": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _f, _i32, _fp, _fp]),
     "swg_train_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),
     "swg_edm_coef": (C.c_int, [_i32, _fp, _i32, _i32, _fp, _fp, _fp]),
     "swg_wattn_bwd": (C.c_int, [C.POINTER(SwgBlock), C.POINTER(SwgBlockTrain), _i32, _fp, _fp, _i32, _fp, _fp, _fp, _i32,

@@ -1008,3 +1008,54 @@ int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, c
 }
 
 }  // extern "C"
+
+// ---- swg_edm_loss_noalloc: the loss without a caller workspace (for callers that cannot allocate) ------------
+// The per-graph partial sums (S_b, n_b) of k_edm_loss_sums live in a file-scope device array instead of the
+// caller's scratch2B.  `scratch` below is the HOST-side stand-in of that array: host code only ever uses the
+// per-device address obtained once through hipGetSymbolAddress.
+#define SWG_LOSS_NOALLOC_MAX_B 65536
+static __device__ __align__(256) float scratch[2 * SWG_LOSS_NOALLOC_MAX_B];  // 512 KiB per GPU the library runs on
+
+#include <mutex>
+namespace {
+constexpr int kMaxDevices = 64;
+std::mutex g_scratch_mu;
+float* g_scratch_ptr[kMaxDevices] = {};  // device address of `scratch` on each GPU, filled on first use there
+
+// device address of this GPU's copy of `scratch` (the current device must be the one `stream` belongs to)
+int loss_scratch_ptr(float** out) {
+  int dev = -1;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  if (dev < 0 || dev >= kMaxDevices) return SWG_E_UNSUPPORTED;
+  std::lock_guard<std::mutex> lk(g_scratch_mu);
+  if (!g_scratch_ptr[dev]) {
+    float* ptr = nullptr;
+    e = hipGetSymbolAddress((void**)&ptr, HIP_SYMBOL(scratch));
+    if (e != hipSuccess) return (int)e;
+    if (!ptr) return SWG_E_NULL;
+    g_scratch_ptr[dev] = ptr;
+  }
+  *out = g_scratch_ptr[dev];
+  return 0;
+}
+}  // namespace
+
+extern "C" int swg_edm_loss_noalloc(int32_t B, int32_t N, const float* pred, const float* target,
+                                    const float* node_flags, const float* weights, float regression_loss_weight,
+                                    int32_t reduction_mean, float* loss, void* stream) {
+  if (!pred || !target || !node_flags || !loss) return SWG_E_NULL;
+  if (B <= 0 || N <= 0) return SWG_E_SHAPE;
+  if (B > SWG_LOSS_NOALLOC_MAX_B) return SWG_E_WORKSPACE;  // beyond the static array: use swg_edm_loss
+  float* ptr = nullptr;
+  const int rc = loss_scratch_ptr(&ptr);
+  if (rc != 0) return rc;
+  // every slot b < B of both halves is overwritten by k_edm_loss_sums before k_edm_loss_finish reads it, so the
+  // previous call's contents need no clearing
+  hipLaunchKernelGGL(k_edm_loss_sums, dim3(B), dim3(256), 0, (hipStream_t)stream, N, pred, target, node_flags, weights,
+                     ptr, ptr + SWG_LOSS_NOALLOC_MAX_B);
+  hipLaunchKernelGGL(k_edm_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, B, ptr, ptr + SWG_LOSS_NOALLOC_MAX_B,
+                     regression_loss_weight, reduction_mean, loss);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
