@@ -7,7 +7,8 @@ import ctypes as C
 import os
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "libswingnn_hip.so")
+# SWG_LIB: another build of the same library (A/B timing of kernel variants in scripts/); never a different backend
+LIB_PATH = os.environ.get("SWG_LIB") or os.path.join(_HERE, "libswingnn_hip.so")
 
 SWG_NOISE_EMB = 512
 ERRORS = {-1: "SWG_E_SHAPE", -2: "SWG_E_UNSUPPORTED", -3: "SWG_E_WORKSPACE", -4: "SWG_E_NULL"}

@@ -24,8 +24,13 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // bind to the int overload and silently drops every term above 2^31 (a workspace plan that shrinks as the batch grows)
 static inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
 
-// x * sigmoid(x) with the hardware reciprocal (1 ulp): a true IEEE division costs ~10 VALU instructions
-__device__ __forceinline__ float silu_f(float v) { return v * __frcp_rn(1.0f + __expf(-v)); }
+// x * sigmoid(x) with the hardware reciprocal and exponential (v_rcp_f32 / v_exp_f32, 1 ulp each).  NOT __frcp_rn:
+// hipcc lowers that to the correctly rounded division (v_div_scale x2, v_div_fmas, v_div_fixup, 4 fmas: ~12 VALU
+// instructions per element, which made the conditioning prologues the largest VALU item of the fused kernels).
+__device__ __forceinline__ float fast_rcp(float v) { return __builtin_amdgcn_rcpf(v); }
+__device__ __forceinline__ float silu_f(float v) {
+  return v * __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896340736f));
+}
 // 1/sqrt(var + eps) of LayerNorm (v_rsq_f32, 1 ulp)
 __device__ __forceinline__ float ln_rstd(float var) { return __frsqrt_rn(var + 1e-5f); }
 // nn.GELU() (exact erf form, model/swin_gnn/swin_gnn.py:10,15) evaluated as x * sigmoid(x * P(x^2)) with a
@@ -93,6 +98,29 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_by
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }
+
+// Diagnostic build only (-DSWG_STAMPS on ONE translation unit, scripts/build_diag.sh): s_memtime stamps of chosen
+// waves go to a buffer of their own that no kernel reads; scripts/diag_stamps.py prints the phase timeline.  The
+// kernel defines `dbg` (bool) and `dbgslot` (0..3) and calls STAMP(i), i < 64.  The shipped library is built without
+// it: STAMP() expands to nothing.
+#ifdef SWG_STAMPS
+__device__ unsigned long long g_stamp[4 * 64];
+#define STAMP(i)                                                           \
+  do {                                                                     \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+    if (dbg) {                                                             \
+      unsigned long long t_ = __builtin_amdgcn_s_memtime();                \
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");                   \
+      if ((threadIdx.x & 63) == 0) g_stamp[dbgslot * 64 + (i)] = t_;       \
+    }                                                                      \
+    __builtin_amdgcn_sched_barrier(0);                                     \
+  } while (0)
+extern "C" int swg_debug_stamps(unsigned long long* host_out, int n) {
+  return (int)hipMemcpyFromSymbol(host_out, HIP_SYMBOL(g_stamp), sizeof(unsigned long long) * n);
+}
+#else
+#define STAMP(i)
+#endif
 
 // ---- row-kernel launch geometry: a row of `chunks` float4 is handled by LANES lanes x V chunks ----
 struct RowGeom {

@@ -157,7 +157,7 @@ __global__ __launch_bounds__(256) void k_wattn_core(WattnArgs a) {
       }
     sum += __shfl_xor(sum, 16, 64);
     sum += __shfl_xor(sum, 32, 64);
-    inv_sum[qt] = __frcp_rn(sum);
+    inv_sum[qt] = fast_rcp(sum);
   }
 
   __syncthreads();  // V rows visible

@@ -34,14 +34,17 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
   constexpr int SLAB = 2 * KS;           // fragments per slab (== NT)
   constexpr int FRAGS_HEAD = 4 * SLAB;   // V, Q, K, P
   constexpr int HEAD_BYTES = FRAGS_HEAD * 1024;
-  constexpr bool FUSE_PROJ = true;
   static_assert(FRAGS_HEAD % (AHEAD + 1) == 0, "the register fragment ring must line up across heads");
-  constexpr int W2 = 2 * WIN - 1, NB = W2 * W2;
+  constexpr int W2 = 2 * WIN - 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   const int wbytes = a.heads * HEAD_BYTES;                            // resident weights (+ AHEAD KiB read-ahead slack)
   float* s_qkvb = reinterpret_cast<float*>(smem + wbytes + AHEAD * 1024);  // [3C], q part pre-scaled
   float* s_pb = s_qkvb + 3 * C;                                       // [C]
-  float* s_rpb = s_pb + C;                                            // [heads][NB] * log2(e)
+  // relative-position bias (:121-124) in ACCUMULATOR layout, one f32x4 per lane and (head, key tile, query tile):
+  // element r of lane (lg, l15) is bias[key kt*16+4lg+r][query qt*16+l15] * log2(e); keys beyond the window carry
+  // -3e38.  One conflict-free ds_read_b128 gives the initial accumulator of S^T = K Q^T: no per-score add, no index
+  // tables in registers.
+  f32x4* s_bias = reinterpret_cast<f32x4*>(s_pb + C);                 // [heads][NTM][NTM][64]
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -60,9 +63,19 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
   }
   for (int i = tid; i < 3 * C; i += 64 * NW) s_qkvb[i] = a.qkv_b[i] * (i < C ? QSCALE : 1.0f);
   for (int i = tid; i < C; i += 64 * NW) s_pb[i] = a.proj_b[i];
-  for (int i = tid; i < NB * a.heads; i += 64 * NW) {
-    const int hh = i / NB, idx = i - hh * NB;
-    s_rpb[i] = a.rpb[idx * a.heads + hh] * LOG2E;
+  for (int e = tid; e < a.heads * NTM * NTM * 64; e += 64 * NW) {
+    const int ln = e & 63, t = e >> 6;
+    const int qt = t % NTM, kt = (t / NTM) % NTM, hh = t / (NTM * NTM);
+    const int i = min(qt * 16 + (ln & 15), NTOK - 1);
+    const int iy = i / WIN, ix = i - iy * WIN;
+    f32x4 v;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int j = kt * 16 + 4 * (ln >> 4) + r;
+      const int jy = j / WIN, jx = j - jy * WIN;
+      v[r] = j < NTOK ? a.rpb[((iy - jy + WIN - 1) * W2 + (ix - jx + WIN - 1)) * a.heads + hh] * LOG2E : -3.0e38f;
+    }
+    s_bias[e] = v;
   }
   asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
   __syncthreads();
@@ -76,29 +89,23 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
     __builtin_amdgcn_sched_barrier(0);                                                                  \
   }
 
-  // ---- once per wave: the window-independent part of the token bookkeeping.  Query side: token i = mt*16 + l15;
-  // key side: token j = kt*16 + 4*lg + r.  iyx / kyx hold the in-window coordinates, qrel - krel the byte offset
-  // into a head's relative-position bias column (:110-121) ----
-  int iyx[NTM], kyx[NTM], qrel[NTM], krel[NTM][4];
-  const float kpad = (4 * lg < REM) ? 0.f : -3.0e38f;  // last key tile: keys 4*lg + r exist only below REM
+  // ---- once per wave: in-window coordinates of the lane's query token i = mt*16 + l15 (key side: token
+  // j = kt*16 + 4*lg + r, only needed by the region mask of border windows and by the bias table above) ----
+  int iyx[NTM];
 #pragma unroll
   for (int mt = 0; mt < NTM; ++mt) {
     const int i = min(mt * 16 + l15, NTOK - 1);
     const int iy = i / WIN, ix = i - iy * WIN;
     iyx[mt] = iy | (ix << 8);
-    qrel[mt] = 4 * ((iy + WIN - 1) * W2 + (ix + WIN - 1));
-    kyx[mt] = 0;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int j = min(mt * 16 + 4 * lg + r, NTOK - 1);
-      const int jy = j / WIN, jx = j - jy * WIN;
-      krel[mt][r] = 4 * (jy * W2 + jx);
-      kyx[mt] |= (jy | (jx << 3)) << (6 * r);
-    }
   }
 
   for (int wi_g = blockIdx.x * NW + wave; wi_g < total; wi_g += gridDim.x * NW) {
-    const bool live = true;
+#ifdef SWG_STAMPS
+    const int witer = (wi_g - (blockIdx.x * NW + wave)) / (gridDim.x * NW);
+    const bool dbg = (witer == 3) && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5);
+    const int dbgslot = (blockIdx.x == 0 ? 0 : 2) + (wave == 0 ? 0 : 1);
+#endif
+    STAMP(0);
     const int b = wi_g / nW, wi = wi_g - b * nW;
     const int wy = wi / nwx, wx = wi - wy * nwx;
     // region ids differ inside a window only in the last window row / column of a shifted block
@@ -172,29 +179,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
       }
     }
     asm volatile("" ::: "memory");
-    // region ids (swin_gnn.py:207-226) of the lane's query row (bits 0..3) and its 4 keys (bits 4+4r..), per token
-    // tile: only needed in the border windows of a shifted block
-    int rids[NTM];
-    if (need_mask) {
-#pragma unroll
-      for (int mt = 0; mt < NTM; ++mt) {
-        auto region = [&](int iy, int ix) {
-          const int ys = wy * WIN + iy, xs = wx * WIN + ix;
-          const int ry = ys < a.res - WIN ? 0 : (ys < a.res - a.shift ? 1 : 2);
-          const int rx = xs < a.res - WIN ? 0 : (xs < a.res - a.shift ? 1 : 2);
-          return 3 * ry + rx;
-        };
-        rids[mt] = region(iyx[mt] & 255, iyx[mt] >> 8);
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          const int kk = (kyx[mt] >> (6 * r)) & 63;
-          rids[mt] |= region(kk & 7, kk >> 3) << (4 + 4 * r);
-        }
-      }
-    } else {
-#pragma unroll
-      for (int mt = 0; mt < NTM; ++mt) rids[mt] = 0;
-    }
+    STAMP(1);
     bf16x8 fr[AHEAD + 1];
 #pragma unroll
     for (int p = 0; p < AHEAD; ++p) fr[p] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + p * 1024);
@@ -202,6 +187,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
 #pragma nounroll
     for (int h = 0; h < a.heads; ++h) {
       const char* cb = smem + h * HEAD_BYTES + lane * 16;  // fragments are contiguous across heads
+      STAMP(3 + 8 * h);
       // ---- V [tokens x 32] = A Wv^T (tokens on rows: directly the A operand of O^T = V^T P^T) ----
       bf16x8 qf[NTM], kf[NTM], vf[2][KSP];
       {
@@ -230,6 +216,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
           }
         }
       }
+      STAMP(4 + 8 * h);
         // ---- Q^T, K^T [32 x tokens] = W A^T ; k-slot j of lane group lg is head dim (j<4 ? 4lg+j : 16+4lg+j-4) ----
       {
         f32x4 qa[2][NTM];
@@ -254,6 +241,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
           qf[mt] = f;
         }
       }
+      STAMP(5 + 8 * h);
       {
         f32x4 ka[2][NTM];
 #pragma unroll
@@ -278,36 +266,44 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
         }
       }
 
+      STAMP(6 + 8 * h);
         // ---- S^T = K Q^T (log2 domain), softmax over keys (rows) per query (lane) ----
-      float p[NTM][NTM][4];
+      f32x4 p[NTM][NTM];
+      {
+        const f32x4* bp = s_bias + (size_t)h * (NTM * NTM * 64) + lane;
 #pragma unroll
-      for (int kt = 0; kt < NTM; ++kt)
+        for (int kt = 0; kt < NTM; ++kt)
 #pragma unroll
-        for (int qt = 0; qt < NTM; ++qt) {
-          f32x4 z = {0.f, 0.f, 0.f, 0.f};
-          z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], z, 0, 0, 0);
-          p[kt][qt][0] = z[0]; p[kt][qt][1] = z[1]; p[kt][qt][2] = z[2]; p[kt][qt][3] = z[3];
-        }
-      const char* rp = reinterpret_cast<const char*>(s_rpb + h * NB);
-#pragma unroll
-      for (int kt = 0; kt < NTM; ++kt)
-#pragma unroll
-        for (int qt = 0; qt < NTM; ++qt)
-#pragma unroll
-          for (int r = 0; r < 4; ++r) {
-            float sv = p[kt][qt][r] + *reinterpret_cast<const float*>(rp + (qrel[qt] - krel[kt][r]));
-            if (kt == NTM - 1) sv += kpad;
-            p[kt][qt][r] = sv;
-          }
-      if (need_mask) {  // wave-uniform: only the border windows of shifted blocks pay for the region mask (:207-226)
+          for (int qt = 0; qt < NTM; ++qt) p[kt][qt] = bp[(kt * NTM + qt) * 64];
 #pragma unroll
         for (int kt = 0; kt < NTM; ++kt)
 #pragma unroll
           for (int qt = 0; qt < NTM; ++qt)
-#pragma unroll
-            for (int r = 0; r < 4; ++r)
-              if (((rids[kt] >> (4 + 4 * r)) & 15) != (rids[qt] & 15)) p[kt][qt][r] += -100.0f * LOG2E;
+            p[kt][qt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], p[kt][qt], 0, 0, 0);
       }
+      if (need_mask) {  // wave-uniform: only the border windows of shifted blocks pay for the region mask (:207-226)
+        auto region = [&](int iy, int ix) {
+          const int ys = wy * WIN + iy, xs = wx * WIN + ix;
+          const int ry = ys < a.res - WIN ? 0 : (ys < a.res - a.shift ? 1 : 2);
+          const int rx = xs < a.res - WIN ? 0 : (xs < a.res - a.shift ? 1 : 2);
+          return 3 * ry + rx;
+        };
+        int rq[NTM];
+#pragma unroll
+        for (int qt = 0; qt < NTM; ++qt) rq[qt] = region(iyx[qt] & 255, iyx[qt] >> 8);
+#pragma unroll
+        for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            const int j = min(kt * 16 + 4 * lg + r, NTOK - 1);
+            const int jy = j / WIN, jx = j - jy * WIN;
+            const int rk = region(jy, jx);
+#pragma unroll
+            for (int qt = 0; qt < NTM; ++qt)
+              if (rk != rq[qt]) p[kt][qt][r] += -100.0f * LOG2E;
+          }
+      }
+      STAMP(7 + 8 * h);
       float inv_sum[NTM];
 #pragma unroll
       for (int qt = 0; qt < NTM; ++qt) {
@@ -327,9 +323,10 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
             sum += e;
           }
         sum = rows_sum(sum);
-        inv_sum[qt] = __frcp_rn(sum);
+        inv_sum[qt] = fast_rcp(sum);
       }
 
+      STAMP(8 + 8 * h);
       // ---- O^T = V^T P^T ; channel slot h*32 + 8*lg + e of a row holds head dim pi(lg, e) ----
       bf16x8 of[NTM];
 #pragma unroll
@@ -357,6 +354,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
         f[4] = (bf16)(o1[0] * is); f[5] = (bf16)(o1[1] * is); f[6] = (bf16)(o1[2] * is); f[7] = (bf16)(o1[3] * is);
         of[qt] = f;
       }
+      STAMP(9 + 8 * h);
         {
         // ---- out^T += Wp_h O^T (Wproj columns carry the head-dim slot order, rows the rho order, in the image) ----
         __builtin_amdgcn_sched_barrier(0);
@@ -368,6 +366,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
       }
     }
 
+    STAMP(27);
     // ---- epilogue: scatter back to token order (shortcut and bias are already in the accumulators) ----
 #pragma unroll
     for (int mt = 0; mt < NTM; ++mt) {
@@ -390,9 +389,9 @@ bool wattn_res_supported(int C, int heads, int win, int res) {
 namespace {
 template <int WIN>
 int launch_res_t(const ResAttnArgs& a, int total, hipStream_t s) {
-  constexpr int C = 96, NW = 8, AHEAD = 3, NB = (2 * WIN - 1) * (2 * WIN - 1);
-  const size_t lds = (size_t)a.heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 +
-                     (size_t)(4 * C + NB * a.heads) * sizeof(float);
+  constexpr int C = 96, NW = 8, AHEAD = 3, NTM = (WIN * WIN + 15) / 16;
+  const size_t lds = (size_t)a.heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 + (size_t)(4 * C) * sizeof(float) +
+                     (size_t)a.heads * NTM * NTM * 1024;  // weights + read-ahead slack + biases + bias tiles
   const int nwg = min(cdiv(total, NW), 256);
   static bool attr_set = false;
   if (!attr_set) {

@@ -87,6 +87,11 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   // region ids differ inside a window only in the last window row / column of a shifted block
   const bool need_mask = __builtin_amdgcn_readfirstlane((int)(a.shift > 0 && (wy == nwx - 1 || wx == nwx - 1))) != 0;
   const int nunits = UH * a.heads;
+#ifdef SWG_STAMPS
+  const bool dbg = (blockIdx.x == 8 || blockIdx.x == gridDim.x / 2) && (wave == 0 || wave == 2);
+  const int dbgslot = (blockIdx.x == 8 ? 0 : 2) + (wave == 0 ? 0 : 1);
+#endif
+  STAMP(0);
 
   const unsigned smem0 = lds_addr(smem);
   const char* img_lane = reinterpret_cast<const char*>(a.img) + lane * 16;
@@ -236,9 +241,11 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
     }
   }
 
+  STAMP(1);
   // unit 0 has landed everywhere (and the tables are visible): start the fragment ring
   wait_vmcnt<(NBUF - 2) * PIECES>();
   __syncthreads();
+  STAMP(2);
   bf16x8 fr[AHEAD + 1];
 #pragma unroll
   for (int p = 0; p < AHEAD; ++p) fr[p] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + p * 1024);
@@ -284,6 +291,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       }
     }
 
+    if (h < 3) STAMP(3 + 8 * h);
     // ---- V [tokens x 32] = A Wv^T (tokens on rows: directly the A operand of O^T = V^T P^T) ----
     bf16x8 qf[NTM], kf[NTM], vf[2][KSP];
     {
@@ -312,6 +320,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
         }
       }
     }
+    if (h < 3) STAMP(4 + 8 * h);
       // ---- Q^T, K^T [32 x tokens] = W A^T ; k-slot j of lane group lg is head dim (j<4 ? 4lg+j : 16+4lg+j-4) ----
     {
       f32x4 qa[2][NTM];
@@ -336,6 +345,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
         qf[mt] = f;
       }
     }
+    if (h < 3) STAMP(5 + 8 * h);
     {
       f32x4 ka[2][NTM];
 #pragma unroll
@@ -360,6 +370,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       }
     }
 
+    if (h < 3) STAMP(6 + 8 * h);
       // ---- S^T = K Q^T (log2 domain), softmax over keys (rows) per query (lane) ----
     float p[NTM][NTM][4];
 #pragma unroll
@@ -390,6 +401,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
           for (int r = 0; r < 4; ++r)
             if (((rids[kt] >> (4 + 4 * r)) & 15) != (rids[qt] & 15)) p[kt][qt][r] += -100.0f * LOG2E;
     }
+    if (h < 3) STAMP(7 + 8 * h);
     float inv_sum[NTM];
 #pragma unroll
     for (int qt = 0; qt < NTM; ++qt) {
@@ -409,9 +421,10 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
           sum += e;
         }
       sum = rows_sum(sum);
-      inv_sum[qt] = __frcp_rn(sum);
+      inv_sum[qt] = fast_rcp(sum);
     }
 
+    if (h < 3) STAMP(8 + 8 * h);
     // ---- O^T = V^T P^T ; channel slot h*32 + 8*lg + e of a row holds head dim pi(lg, e) ----
     bf16x8 of[NTM];
 #pragma unroll
@@ -443,6 +456,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
           *reinterpret_cast<bf16x8*>(a.o + (size_t)tokq[qt] * a.ldo + h * 32 + 8 * lg) = f;
       }
     }
+    if (h < 3) STAMP(9 + 8 * h);
       if (FUSE_PROJ) {
       // ---- out^T += Wp_h O^T (Wproj columns carry the head-dim slot order, rows the rho order, in the image) ----
       __builtin_amdgcn_sched_barrier(0);
@@ -458,6 +472,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
     }
 #undef GROUP
 #undef STAGE_PIECE
+  STAMP(27);
   wait_vmcnt<0>();  // trailing refills have landed before the workgroup's LDS is released
 
   if (FUSE_PROJ && !PRE_LN) {
