@@ -72,7 +72,7 @@ def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
     with torch.no_grad():
         den(O.gen_init_sample(flags) * 80.0, flags, torch.full((1,), 80.0), None)  # warm-up call
         per_call = calls[-1]
-        steps = int(max(2, min(8, seconds_budget / max(per_call * 3.0, 1e-3))))
+        steps = int(max(2, min(96, seconds_budget / max(per_call * 2.0, 1e-3))))  # ~10-30 s of CPU work
         calls.clear()
         t0 = time.perf_counter()
         O.edm_sample(den, flags, num_steps=steps, self_condition=True)
@@ -82,6 +82,97 @@ def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
     return dict(value=1.0 / full, unit="graphs/s", cores=torch.get_num_threads(), kind="port",
                 sample=f"oracle/swingnn_ref.py edm_sample, batch 1, {steps} of 256 Heun steps ({2 * steps - 1} "
                        f"preconditioner calls in {dt:.1f} s), extrapolated linearly to 511 calls")
+
+
+def rank_env():
+    """(rank, local_rank, world) from the torchrun environment (utils/dist_training.py:101-126 reads the same)."""
+    return (int(os.environ.get("RANK", "0")), int(os.environ.get("LOCAL_RANK", "0")),
+            int(os.environ.get("WORLD_SIZE", "1")))
+
+
+def timed_steps(step_fn, steps, warmup, sync, dist=None, device=None):
+    """The driver's timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier +
+    device sync on both sides; returns the MAX over ranks of the wall time (seconds).  `sync` = device synchronise
+    (torch.cuda.synchronize on the GPU, a no-op in the CPU/gloo test)."""
+    def barrier():
+        sync()
+        if dist is not None:
+            dist.barrier()
+            sync()
+
+    for _ in range(warmup):
+        step_fn()
+    barrier()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        step_fn()
+    barrier()
+    dt = time.perf_counter() - t0
+    if dist is not None:
+        t = torch.tensor([dt], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        dt = float(t.item())
+    return dt
+
+
+def whole_job_value(batch_per_rank, world, steps, dt_max):
+    """graphs all ranks sampled / max-over-ranks wall time: the aggregate the JSON line reports as `value`."""
+    return batch_per_rank * world * steps / dt_max
+
+
+def roofline_objects(kern, batch, config):
+    """`roofline` (ONE kernel symbol: the one with the largest share of GPU time) and `window_attn` (the fused
+    window-attention kernel of every stage against the dense bf16 MFMA peak) from the library profiler's tallies
+    {symbol: dict(ms, flops, bytes, launches)}.  Formulas: DESIGN.md section 4."""
+    total_ms = sum(k["ms"] for k in kern.values())
+    name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+    avg_s = dom["ms"] * 1e-3 / dom["launches"]
+    ai = dom["flops"] / max(dom["bytes"], 1.0)
+    if ai >= MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
+        achieved = dom["flops"] / dom["launches"] / avg_s / 1e12
+        roof = dict(bound="mfma", achieved=achieved, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
+                    frac=achieved / MFMA_BF16_PEAK_TFLOPS)
+    else:
+        achieved = dom["bytes"] / dom["launches"] / avg_s / 1e9
+        roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
+    # HBM bytes per launch of that symbol from the PMC passes committed under profiles/ (rocprofv3 cannot run inside
+    # this process; scripts/pmc_traffic.sh collects them with the same batch).  null when no profile fits.
+    traffic, traffic_src = None, None
+    if config == "grid":
+        import glob
+        for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
+            prof_json = json.load(open(path))
+            if prof_json.get("batch", 56) == batch and name in prof_json["kernels"]:
+                traffic = prof_json["kernels"][name]["hbm_bytes_per_launch"]
+                traffic_src = os.path.relpath(path, ROOT) + ": " + prof_json["method"]
+                break
+    roof.update(kernel=name, traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
+                algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"],
+                algorithmic_flops_per_launch=dom["flops"] / dom["launches"], avg_launch_us=avg_s * 1e6,
+                launches=dom["launches"], share_of_gpu_time=dom["ms"] / total_ms,
+                tflops=dom["flops"] / (dom["ms"] * 1e-3) / 1e12, algorithmic_GBs=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
+                kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
+                                 tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
+                                 GBs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in kern.items()},
+                sample="4-step sample() replay, same batch, profiler on (untimed)")
+    stages = {"s0_C96": "k_wattn_res", "s1_C192": "k_wattn_ring<192>", "s2_C384": "k_wattn_ring<384>",
+              "s3_C768_core_only": "k_wattn_core"}
+    wattn = {"peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
+             "flops": "8 T C^2 + 4 n T C per launch (QKV + proj + QK^T + PV; 6 T C^2 where the projection is a "
+                      "separate GEMM: s2; 4 n T C for the attention core alone: s3)"}
+    fl = ms = 0.0
+    for stage, sym in stages.items():
+        if sym in kern:
+            v = kern[sym]
+            tf = v["flops"] / (v["ms"] * 1e-3) / 1e12
+            wattn[stage] = dict(kernel=sym, tflops=round(tf, 1), mfma_util_pct=round(100.0 * tf / MFMA_BF16_PEAK_TFLOPS, 2),
+                                avg_launch_us=round(v["ms"] * 1e3 / v["launches"], 1), launches=v["launches"])
+            if sym != "k_wattn_core":
+                fl += v["flops"]
+                ms += v["ms"]
+    if ms > 0:
+        wattn["fused_kernels_mfma_util_pct"] = round(100.0 * fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 2)
+    return roof, wattn
 
 
 def main():
@@ -97,9 +188,7 @@ def main():
     ap.add_argument("--no-pass-reuse", action="store_true", help="skip the extra (non-headline) run with reuse_passes")
     args = ap.parse_args()
 
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank, local_rank, world = rank_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
@@ -125,21 +214,16 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
+    last = {}
+
+    def one_step():
+        last["out"] = sampler.sample(model, flags)
+
     with torch.no_grad():
-        for _ in range(args.warmup):
-            sampler.sample(model, flags)
-        barrier()
-        t0 = time.perf_counter()
-        for _ in range(args.steps):
-            out = sampler.sample(model, flags)
-        barrier()
-        dt = time.perf_counter() - t0
+        dt = timed_steps(one_step, args.steps, args.warmup, torch.cuda.synchronize, dist if world > 1 else None, dev)
+    out = last["out"]
     assert torch.isfinite(out).all()
     from swingnn_amd import engine as _E
-    if world > 1:
-        t = torch.tensor([dt], device=dev, dtype=torch.float64)
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        dt = float(t.item())
     # ---- extra, NOT the headline value: the same workload with EDMSampler.reuse_passes (network passes of a Heun step
     # that repeat an evaluation at the same (x_hat, sigma_hat) are reused; bit-identical samples) ----
     reuse = None
@@ -171,41 +255,11 @@ def main():
         with torch.no_grad(), prof.profiled():
             short.sample(model, flags)
         kern = prof.read()
-        total_ms = sum(k["ms"] for k in kern.values())
-        name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
-        avg_s = dom["ms"] * 1e-3 / dom["launches"]
-        ai = dom["flops"] / max(dom["bytes"], 1.0)
-        if ai >= MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9):
-            achieved = dom["flops"] / dom["launches"] / avg_s / 1e12
-            roof = dict(bound="mfma", achieved=achieved, peak=MFMA_BF16_PEAK_TFLOPS, unit="TFLOP/s",
-                        frac=achieved / MFMA_BF16_PEAK_TFLOPS)
-        else:
-            achieved = dom["bytes"] / dom["launches"] / avg_s / 1e9
-            roof = dict(bound="hbm", achieved=achieved, peak=HBM_PEAK_GBS, unit="GB/s", frac=achieved / HBM_PEAK_GBS)
-        # HBM bytes per launch of that kernel from the PMC passes committed under profiles/ (rocprofv3 cannot run
-        # inside this process; scripts/pmc_traffic.sh collects them with the same batch).  null when no profile fits.
-        traffic, traffic_src = None, None
-        if args.config == "grid":
-            import glob
-            for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
-                prof_json = json.load(open(path))
-                if prof_json.get("batch", 56) == args.batch and name in prof_json["kernels"]:
-                    traffic = prof_json["kernels"][name]["hbm_bytes_per_launch"]
-                    traffic_src = os.path.relpath(path, ROOT) + ": " + prof_json["method"]
-                    break
-        roof.update(kernel=name, traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
-                    algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"], avg_launch_us=avg_s * 1e6, launches=dom["launches"],
-                    share_of_gpu_time=dom["ms"] / total_ms,
-                    tflops=dom["flops"] / (dom["ms"] * 1e-3) / 1e12, algorithmic_GBs=dom["bytes"] / (dom["ms"] * 1e-3) / 1e9,
-                    kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
-                                     tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
-                                     GBs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in kern.items()},
-                    sample="4-step sample() replay, same batch, profiler on (untimed)")
-        graphs = args.batch * world * args.steps
+        roof, wattn = roofline_objects(kern, args.batch, args.config)
         result = {
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.config == "grid"
             else f"sampled graphs/sec, EDM {args.config}",
-            "value": graphs / dt, "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "value": whole_job_value(args.batch, world, args.steps, dt), "unit": "graphs/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": dt / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
             "dtype": "bf16 MFMA operands, fp32 accumulate/state", "data": "synthetic",
             "config": {"workload": f"{args.config} EDM Heun sampling: N={cfg['img_size']}, nodes {cfg['n_nodes']}, "
@@ -214,6 +268,7 @@ def main():
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
                        "parallelism": f"independent replicas x{world} (batch-sharded, no collective)"},
             "roofline": roof,
+            "window_attn": wattn,
         }
         if reuse is not None:
             result["pass_reuse"] = reuse

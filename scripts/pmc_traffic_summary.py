@@ -10,8 +10,10 @@ def short(name):
     name = name.replace("(anonymous namespace)::", "").replace("void ", "")
     m = re.match(r"([A-Za-z_0-9]+)(<[^>]*>)?", name)
     base = m.group(1)
-    base = {"k_patch_embed_mfma": "k_patch_embed", "k_final_readout_mfma": "k_final_readout",
-            "k_gemm_nt_big": "k_gemm_nt"}.get(base, base)  # the names the library's own profiler tallies under
+    base = {"k_patch_embed_mfma": "k_patch_embed", "k_final_readout_mfma": "k_final_readout"}.get(base, base)
+    # the names the library's own profiler tallies under (prof.hip): one per kernel symbol
+    if base in ("k_gemm_nt", "k_mlp_stream", "k_wattn_ring") and m.group(2):
+        return base + "<" + m.group(2).strip("<>").split(",")[0].strip() + ">"
     if base == "k_row" and m.group(2):
         mode = m.group(2).strip("<>").split(",")[-1].strip()
         base += "<" + {"0": "cond_ln", "1": "merge_ln", "2": "concat", "3": "ln_f32", "4": "breakup_ln"}.get(mode, mode) + ">"

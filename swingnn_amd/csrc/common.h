@@ -17,6 +17,22 @@ typedef __attribute__((ext_vector_type(4))) float f32x4;
     if (e__ != hipSuccess) return (int)e__;        \
   } while (0)
 
+// Opt-in to more than 64 KiB of dynamic LDS, once per (kernel instantiation, DEVICE): `done` is the call site's
+// bit-per-device record (the attribute belongs to the device's copy of the code object, so a second GPU in the same
+// process needs its own call; a plain `static bool` would skip it).  Thread-safe; returns 0 or a hipError_t.
+#include <atomic>
+static inline int ensure_dyn_lds(std::atomic<uint64_t>& done, const void* fn, int bytes) {
+  int dev = 0;
+  hipError_t e = hipGetDevice(&dev);
+  if (e != hipSuccess) return (int)e;
+  const uint64_t bit = 1ull << (dev & 63);
+  if (done.load(std::memory_order_acquire) & bit) return 0;
+  e = hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) return (int)e;
+  done.fetch_or(bit, std::memory_order_release);
+  return 0;
+}
+
 static inline int cdiv(int a, int b) { return (a + b - 1) / b; }
 static inline int round_up(int a, int b) { return cdiv(a, b) * b; }
 static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }

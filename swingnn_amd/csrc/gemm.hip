@@ -516,7 +516,7 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
   while (S > 1 && (size_t)S * Mo * No > partial_floats) --S;
   int kslice = round_up(cdiv(rows, S), TN_BT);
   S = cdiv(rows, kslice);
-  SwgProfScope ps(KID_GEMM, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
+  SwgProfScope ps(KID_GEMM_TN, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
                                                            8.0 * Mo * (double)No, s);
   if (S <= 1) {
     hipLaunchKernelGGL(k_gemm_tn, dim3(8 * tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, tiles, 1, kslice,
@@ -546,8 +546,7 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
   const int tiles_m = cdiv(M, BM), tiles_n = cdiv(ee.n_store, BN);
   const int nwg = tiles_m * tiles_n;
   const double osz = ee.out_f32 ? 4.0 : 2.0;
-  SwgProfScope ps(KID_GEMM, 2.0 * M * (double)N * Kp,
-                  2.0 * M * Kp + 2.0 * N * (double)Kp + osz * M * (double)N + (ee.residual ? 4.0 * M * (double)N : 0.0), s);
+
   // BK = 32 halves the LDS footprint (4 workgroups per CU instead of 2): with many row panels in flight the extra
   // residency hides the short-K prologue / epilogue better than the longer k-step amortises its barrier (measured
   // per shape, scripts/bench_gemm.py: +5..25 % for M >= 32k, -3..10 % for M = 8k)
@@ -562,6 +561,9 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
     // panels; short-K fp32 + residual shapes (epilogue-bound) keep the small form's higher workgroup residency
     form = (big_wg >= 384 && (ee.n_store >= 1024 || M >= 131072 || (ee.n_store >= 768 && M >= 65536))) ? 3 : 1;
   }
+  const int kid = form == 3 ? KID_GEMM_NT_BIG : ((Kp % 64 == 0 && M < 16384) ? KID_GEMM_NT64 : KID_GEMM);
+  SwgProfScope ps(kid, 2.0 * M * (double)N * Kp,
+                  2.0 * M * Kp + 2.0 * N * (double)Kp + osz * M * (double)N + (ee.residual ? 4.0 * M * (double)N : 0.0), s);
   if (form == 3) {
     hipLaunchKernelGGL((k_gemm_nt_big<8, 3>), dim3(big_wg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n);
     SWG_LAUNCH_CHECK();

@@ -226,13 +226,8 @@ int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, 
   const size_t lds = (size_t)2 * (2 * HC * C) * 2 + (size_t)4 * C * sizeof(float);
   SwgProfScope ps(KID_FUSED_MLP, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
   dim3 grid(cdiv(T, 128)), block(256);
-  static bool attr_set = false;  // dynamic LDS above 64 KiB needs an explicit opt-in (C = 192: 96 KiB)
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_fused<192, false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                       2 * (2 * HC * 192) * 2 + 4 * 192 * 4);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_fused<192, false>, (int)(2 * (2 * HC * 192) * 2 + 4 * 192 * 4))) return e;
   if (C == 96) hipLaunchKernelGGL((k_mlp_fused<96, true>), grid, block, lds, s, a);
   else hipLaunchKernelGGL((k_mlp_fused<192, false>), grid, block, lds, s, a);
   SWG_LAUNCH_CHECK();

@@ -265,13 +265,8 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
 template <int C, int HC, int NBUF, int LB>
 int launch_one(const MlpArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)NBUF * (4 * HC * C) + (size_t)(4 * C + 2 * HC) * sizeof(float);
-  static bool attr_set = false;  // dynamic LDS above 64 KiB needs an explicit opt-in
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_mlp_stream<C, HC, NBUF, LB>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_stream<C, HC, NBUF, LB>, (int)((int)lds))) return e;
   hipLaunchKernelGGL((k_mlp_stream<C, HC, NBUF, LB>), dim3(cdiv(a.T, 128)), dim3(256), lds, s, a);
   return 0;
 }
@@ -285,7 +280,7 @@ int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img,
   if (!mlp_stream_supported(C)) return SWG_E_UNSUPPORTED;
   if (T <= 0) return 0;
   MlpArgs a = {x, out, img, b1, b2, g, b, T};
-  SwgProfScope ps(KID_MLP_STREAM, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
+  SwgProfScope ps(C == 384 ? KID_MLP_STREAM_384 : KID_MLP_STREAM, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
   int rc = (C == 384) ? launch_one<384, 32, 3, 1>(a, s) : launch_one<192, 64, 3, 1>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();

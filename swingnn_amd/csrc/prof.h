@@ -29,6 +29,12 @@ enum SwgKernelId {
   KID_WATTN_BWD,
   KID_OPTIM,
   KID_NODEADJ,
+  // one id per kernel SYMBOL where a launcher picks between instantiations (bench.py's roofline names one symbol)
+  KID_GEMM_NT64,
+  KID_GEMM_NT_BIG,
+  KID_GEMM_TN,
+  KID_MLP_STREAM_384,
+  KID_WATTN_RING_384,
   KID_COUNT
 };
 

@@ -23,13 +23,14 @@ struct Prof {
   std::mutex mu;
 } P;
 
-const char* kNames[KID_COUNT] = {"k_gemm_nt",      "k_wattn_core",  "k_row<cond_ln>", "k_row<merge_ln>",
+const char* kNames[KID_COUNT] = {"k_gemm_nt<32>",    "k_wattn_core",  "k_row<cond_ln>", "k_row<merge_ln>",
                                  "k_row<concat>",  "k_row<ln_f32>", "k_row<breakup_ln>", "k_gemv_rows",
                                  "k_pos_embed",    "k_edm_coef",    "k_patch_embed",  "k_final_readout",
                                  "k_sym_precond",  "k_heun",        "k_wattn_fused",  "k_mlp_fused",
-                                 "k_mlp_stream",   "k_wattn_ring",  "k_wattn_res",    "k_breakup_post",
+                                 "k_mlp_stream<192>", "k_wattn_ring<192>", "k_wattn_res",   "k_breakup_post",
                                  "bwd_rows",       "k_wattn_bwd",   "k_adam_ema",
-                                 "k_nodeadj"};
+                                 "k_nodeadj",      "k_gemm_nt<64>", "k_gemm_nt_big",  "k_gemm_tn",
+                                 "k_mlp_stream<384>", "k_wattn_ring<384>"};
 
 void drain() {  // caller holds the lock; synchronises the recorded events
   for (size_t i = 0; i < P.used; ++i) {

@@ -393,13 +393,8 @@ int launch_res_t(const ResAttnArgs& a, int total, hipStream_t s) {
   const size_t lds = (size_t)a.heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 + (size_t)(4 * C) * sizeof(float) +
                      (size_t)a.heads * NTM * NTM * 1024;  // weights + read-ahead slack + biases + bias tiles
   const int nwg = min(cdiv(total, NW), 256);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_res<C, NW, AHEAD, WIN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_res<C, NW, AHEAD, WIN>, (int)((int)lds))) return e;
   hipLaunchKernelGGL((k_wattn_res<C, NW, AHEAD, WIN>), dim3(nwg), dim3(64 * NW), lds, s, a);
   return 0;
 }

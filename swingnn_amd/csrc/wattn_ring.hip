@@ -69,6 +69,11 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   static_assert(FRAGS_HEAD % (AHEAD + 1) == 0, "the register fragment ring must line up across heads");
   static_assert((NBUF - 2) * PIECES < 64, "vmcnt is 6 bits");
   constexpr int W2 = 2 * WIN - 1, NB = W2 * W2;
+  // 6x6 windows: the 36 bias values of a lane (3 x 3 tile pairs x 4 accumulator rows) are read straight into the
+  // accumulators of S^T = K Q^T through 36 head-invariant LDS offsets kept in registers; entry NB of a head's table is
+  // the key padding (-3e38).  8x8 windows (64 offsets) keep the index arithmetic: C = 192 is at the register limit.
+  constexpr bool BIAS_REGS = (WIN == 6);
+  constexpr int NBP = NB + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_qkvb = reinterpret_cast<float*>(smem + RING_BYTES);  // [3C], q part pre-scaled
   float* s_pb = s_qkvb + 3 * C;                                 // [C]
@@ -156,9 +161,9 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   for (int i = tid; i < 3 * C; i += 256) s_qkvb[i] = a.qkv_b[i] * (i < C ? QSCALE : 1.0f);
   if (FUSE_PROJ)
     for (int i = tid; i < C; i += 256) s_pb[i] = a.proj_b[i];
-  for (int i = tid; i < NB * a.heads; i += 256) {
-    const int hh = i / NB, idx = i - hh * NB;
-    s_rpb[i] = a.rpb[idx * a.heads + hh] * LOG2E;
+  for (int i = tid; i < NBP * a.heads; i += 256) {
+    const int hh = i / NBP, idx = i - hh * NBP;
+    s_rpb[i] = idx < NB ? a.rpb[idx * a.heads + hh] * LOG2E : -3.0e38f;
   }
   if (!PRE_LN) {
 #pragma unroll
@@ -224,6 +229,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 #pragma unroll
     for (int i = 0; i < PIECES; ++i) STAGE_PIECE(min(u, nunits - 1), u * UNIT_BYTES, i);
   int qrel[NTM], krel[NTM][4], rids[NTM];
+  int boff[BIAS_REGS ? NTM : 1][BIAS_REGS ? NTM : 1][4];
   const float kpad = (4 * lg < REM) ? 0.f : -3.0e38f;  // last key tile: keys 4*lg + r exist only below REM
 #pragma unroll
   for (int mt = 0; mt < NTM; ++mt) {
@@ -240,8 +246,17 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       rids[mt] |= jr << (4 + 4 * r);
     }
   }
+  if (BIAS_REGS) {
+#pragma unroll
+    for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+      for (int qt = 0; qt < NTM; ++qt)
+#pragma unroll
+        for (int r = 0; r < 4; ++r)
+          boff[BIAS_REGS ? kt : 0][BIAS_REGS ? qt : 0][r] =
+              (kt * 16 + 4 * lg + r < NTOK) ? qrel[qt] - krel[kt][r] : 4 * NB;
+  }
 
-  STAMP(1);
   // unit 0 has landed everywhere (and the tables are visible): start the fragment ring
   wait_vmcnt<(NBUF - 2) * PIECES>();
   __syncthreads();
@@ -373,25 +388,39 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
     if (h < 3) STAMP(6 + 8 * h);
       // ---- S^T = K Q^T (log2 domain), softmax over keys (rows) per query (lane) ----
     float p[NTM][NTM][4];
+    const char* rp = reinterpret_cast<const char*>(s_rpb + h * NBP);
+    if (BIAS_REGS) {
 #pragma unroll
-    for (int kt = 0; kt < NTM; ++kt)
+      for (int kt = 0; kt < NTM; ++kt)
 #pragma unroll
-      for (int qt = 0; qt < NTM; ++qt) {
-        f32x4 z = {0.f, 0.f, 0.f, 0.f};
-        z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], z, 0, 0, 0);
-        p[kt][qt][0] = z[0]; p[kt][qt][1] = z[1]; p[kt][qt][2] = z[2]; p[kt][qt][3] = z[3];
-      }
-    const char* rp = reinterpret_cast<const char*>(s_rpb + h * NB);
+        for (int qt = 0; qt < NTM; ++qt) {
+          f32x4 z;
 #pragma unroll
-    for (int kt = 0; kt < NTM; ++kt)
-#pragma unroll
-      for (int qt = 0; qt < NTM; ++qt)
-#pragma unroll
-        for (int r = 0; r < 4; ++r) {
-          float sv = p[kt][qt][r] + *reinterpret_cast<const float*>(rp + (qrel[qt] - krel[kt][r]));
-          if (kt == NTM - 1) sv += kpad;
-          p[kt][qt][r] = sv;
+          for (int r = 0; r < 4; ++r)
+            z[r] = *reinterpret_cast<const float*>(rp + boff[BIAS_REGS ? kt : 0][BIAS_REGS ? qt : 0][r]);
+          z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], z, 0, 0, 0);
+          p[kt][qt][0] = z[0]; p[kt][qt][1] = z[1]; p[kt][qt][2] = z[2]; p[kt][qt][3] = z[3];
         }
+    } else {
+#pragma unroll
+      for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NTM; ++qt) {
+          f32x4 z = {0.f, 0.f, 0.f, 0.f};
+          z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], z, 0, 0, 0);
+          p[kt][qt][0] = z[0]; p[kt][qt][1] = z[1]; p[kt][qt][2] = z[2]; p[kt][qt][3] = z[3];
+        }
+#pragma unroll
+      for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NTM; ++qt)
+#pragma unroll
+          for (int r = 0; r < 4; ++r) {
+            float sv = p[kt][qt][r] + *reinterpret_cast<const float*>(rp + (qrel[qt] - krel[kt][r]));
+            if (kt == NTM - 1) sv += kpad;
+            p[kt][qt][r] = sv;
+          }
+    }
     if (need_mask) {  // wave-uniform: only the border windows of shifted blocks pay for the region mask (:207-226)
 #pragma unroll
       for (int kt = 0; kt < NTM; ++kt)
@@ -514,14 +543,9 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 
 template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN>
 int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
-  const size_t lds = (size_t)NBUF * 24 * 1024 + (size_t)(4 * C + (2 * WIN - 1) * (2 * WIN - 1) * a.heads) * sizeof(float);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipError_t e = hipFuncSetAttribute((const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>,
-                                       hipFuncAttributeMaxDynamicSharedMemorySize, (int)lds);
-    if (e != hipSuccess) return (int)e;
-    attr_set = true;
-  }
+  const size_t lds = (size_t)NBUF * 24 * 1024 + (size_t)(4 * C + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
+  static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>, (int)((int)lds))) return e;
   hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>), dim3(nwg), dim3(256), lds, s, a);
   return 0;
 }
@@ -550,7 +574,7 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   const int nwg = cdiv(B * nW, 4);
   const double T = (double)B * blk->res * blk->res;
   const double gemm = wattn_ring_fuses_proj(C) ? 8.0 : 6.0;
-  SwgProfScope ps(KID_WATTN_RING, gemm * T * C * C + 4.0 * T * (blk->win * blk->win) * C,
+  SwgProfScope ps(C == 384 ? KID_WATTN_RING_384 : KID_WATTN_RING, gemm * T * C * C + 4.0 * T * (blk->win * blk->win) * C,
                   (gemm == 8.0 ? 8.0 : 6.0) * T * C + gemm * C * C, s);
   int r;
   if (blk->win == 8) {

@@ -132,6 +132,10 @@ class EDMSampler(GeneralSampler):
 
         x_next = (E._as_f32(init_adjs) * float(self.sigma_steps[0].to(torch.float32))).contiguous()
         x_hat, x_prime, d_cur = torch.empty_like(x_next), torch.empty_like(x_next), torch.empty_like(x_next)
+        # nothing is allocated or copied host -> device inside the loop: the state ping-pongs between two buffers and
+        # every step's sigma_hat sits in one device vector (the model sees a [1] view expanded to [B], edm.py:180)
+        state = [x_next, torch.empty_like(x_next)]
+        sig_all = torch.tensor([c[0] for c in consts], dtype=torch.float32, device=dev)
         x_self_cond = None
         reuse = bool(self.reuse_passes and masked_model and gt is None and hasattr(inner, "_step_memo"))
         for i, (t_hat, coef, h, t_prime) in enumerate(consts):
@@ -141,7 +145,7 @@ class EDMSampler(GeneralSampler):
             raw = self._randn_like(x_cur)
             L.check(lib.swg_heun_churn(B, N, x_cur.data_ptr(), raw.data_ptr(), flags.data_ptr(), coef,
                                        x_hat.data_ptr(), sp()), "swg_heun_churn")
-            sig = torch.full((1,), t_hat, dtype=torch.float32, device=dev).expand(B)
+            sig = sig_all[i:i + 1].expand(B)
             if gt is None:
                 with torch.no_grad():
                     den = model(x_hat, flags, sig, x_self_cond)
@@ -151,7 +155,7 @@ class EDMSampler(GeneralSampler):
             else:
                 den = gt
             last = self.solver == 'euler' or i == self.num_steps - 1
-            x_next = torch.empty_like(x_hat)
+            x_next = state[(i + 1) & 1]
             L.check(lib.swg_heun_euler(B, N, x_hat.data_ptr(), den.data_ptr(), flags.data_ptr(), t_hat, h, int(last),
                                        d_cur.data_ptr(), (x_next if last else x_prime).data_ptr(), sp()),
                     "swg_heun_euler")

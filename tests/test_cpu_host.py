@@ -41,7 +41,7 @@ def test_every_declared_symbol_is_exported_and_bound(S):
     assert declared == set(L.SYMBOLS), declared ^ set(L.SYMBOLS)
     assert L.lib.swg_version() >= 1
     names = {L.lib.swg_prof_name(k).decode() for k in range(L.lib.swg_prof_kernels())}
-    assert "k_gemm_nt" in names and "" not in names
+    assert {"k_gemm_nt<32>", "k_gemm_nt_big", "k_wattn_ring<384>", "k_mlp_stream<384>"} <= names and "" not in names
 
 
 def test_host_only_error_paths(S):
