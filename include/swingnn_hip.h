@@ -391,6 +391,43 @@ int swg_adam_ema_step(const void* p_ptrs, const void* g_ptrs, const int32_t* num
                       float max_norm, float lr, float beta1, float beta2, float eps, float weight_decay, int32_t step,
                       void* stream);
 
+/* ---- post-sampling: attribute codecs of the molecule path -------------------------------- *
+ * utils/attribute_code.py:14-329.  Node attributes [B,N] (int / ddpm) or [B,N,C] (one-hot / bits); adjacency
+ * attributes [B,N,N] or [B,C,N,N]; node_flags [B,N] fp32 0/1 (rows AND columns are masked for adjacency entries).
+ * encoding: 0 ddpm (:124-177 / :241-255), 1 one-hot (:213-238 / :284-305), 2 bits (:180-210 / :258-281).  Integer
+ * attributes travel as fp32 (exact below 2^24), as the reference's float tensors do.
+ * swg_attr_decode: `in` -> integer attribute.  ddpm: interval bounds lo / hi [num_types] (DEVICE arrays: the fp32 casts
+ *   of the reference's doubles, :133-150); C must be 1.  ddpm_range: the one-hot / bits channels are -1/+1 (else 0/1).
+ *   binarise != 0 first applies the sampler's quantisation (runner/sampler/sampler_node_adj.py:179-181, :191-193):
+ *   clamp to [-1,1], then channel > 0 -> +1 else -1.  clamp_int: bits only, clamp to [0, num_types-1] (:203-204).
+ * swg_attr_encode: integer attribute -> `out` in the given encoding (C channels; C = ceil(log2(num_types)) for bits). */
+int swg_attr_decode(int32_t encoding, int32_t B, int32_t N, int32_t C, int32_t num_types, int32_t is_adj,
+                    int32_t ddpm_range, int32_t binarise, int32_t clamp_int, const float* in, const float* node_flags,
+                    const float* lo, const float* hi, float* out_int, void* stream);
+int swg_attr_encode(int32_t encoding, int32_t B, int32_t N, int32_t C, int32_t num_types, int32_t is_adj,
+                    int32_t ddpm_range, const float* in_int, const float* node_flags, float* out, void* stream);
+
+/* ---- post-sampling: binarised-graph statistics and MMD ---------------------------------- *
+ * evaluation/stats.py:26-175 (degree_stats, clustering_stats, spectral_stats) and evaluation/mmd.py:82-163
+ * (gaussian_tv, compute_mmd with is_hist=True) for graphs given as adjacency matrices adj [B,N,N] (any non-zero entry
+ * is an edge; symmetrised, self loops and isolated nodes dropped as adjs_to_graphs does, stats.py:291-305; N <= 1024).
+ * swg_graph_hists: deg_hist [B,N] (nx.degree_histogram, zero padded), clu_hist [B,cluster_bins] (np.histogram of
+ *   nx.clustering over [0,1]), and, when lap != NULL, the normalised Laplacian [B,N,N] whose removed nodes carry
+ *   iso_diag on the diagonal (choose it outside the histogram range: their eigenvalues are then ignored).  All fp64.
+ * swg_hist_pmf: np.histogram(vals[b], bins, range=(first,last)) / count for each row of vals [B,n] (the 200-bin
+ *   spectral pmf of stats.py:133-135 from the Laplacian's eigenvalues).  snap = 0: exactly numpy (a value outside the
+ *   range is dropped); snap > 0: values up to `snap` outside are counted in the end bins (eigenvalues of a normalised
+ *   Laplacian lie in [0,2]; whether a solver returns 2 or 2 + 4e-16 should not decide if a node is counted).
+ * swg_mmd_gaussian_tv: *out = MMD^2 between the histogram sets X [n1,L] and Y [n2,L] (rows zero padded to a common
+ *   L; each row is normalised to sum 1 unless it sums to 0).  scratch: 3*(n1+n2) doubles.  Deterministic order. */
+size_t swg_graph_stats_workspace_bytes(int32_t B, int32_t N);
+int swg_graph_hists(int32_t B, int32_t N, int32_t cluster_bins, const float* adj, double* deg_hist, double* clu_hist,
+                    double* lap, double iso_diag, void* ws, size_t ws_bytes, void* stream);
+int swg_hist_pmf(int32_t B, int32_t n, int32_t bins, const double* vals, double first, double last, double snap,
+                 double* out, void* stream);
+int swg_mmd_gaussian_tv(int32_t n1, int32_t n2, int32_t L, const double* X, const double* Y, double sigma, double* out,
+                        double* scratch, void* stream);
+
 /* ---- derived-operand refresh (no counterpart in the reference, which reads the fp32 parameters directly) ---- *
  * After an optimizer step every bf16 operand derived from the fp32 nn.Parameters (K-padded copies, transposed copies
  * for the backward GEMMs, fragment-order images of the fused kernels) is rewritten IN PLACE by one launch, so the

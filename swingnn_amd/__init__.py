@@ -12,6 +12,7 @@ from .edm_sampler import EDMSampler, GeneralSampler, NodeAdjEDMSampler
 from .objective import EDMObjectiveGenerator, RainbowLoss, NodeAdjEDMObjectiveGenerator, NodeAdjRainbowLoss
 from .optim import FusedAdamEMA
 from .io import load_model, adjs_to_dataset_tensors, quantise_samples
+from . import codec, graph_stats  # noqa: F401  (post-sampling: attribute codecs, graph statistics / MMD on the device)
 
 __all__ = ["SwinGNN", "SwinTransformerBlock", "WindowAttention", "PatchMerging", "PatchBreakup", "PatchEmbed",
            "BasicLayer", "Mlp", "PositionalEmbedding", "Precond", "EDMSampler", "GeneralSampler", "EDMObjectiveGenerator", "RainbowLoss",

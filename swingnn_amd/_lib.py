@@ -158,6 +158,12 @@ SYMBOLS = {
     "swg_grad_sqnorm": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _fp, _fp]),
     "swg_adam_ema_step": (C.c_int, [_fp, _fp, _fp, _fp, _fp, _fp, _i32, _fp, _fp, _fp, C.c_int64, _i32,
                                     C.POINTER(C.c_float), _fp, _f, _f, _f, _f, _f, _f, _i32, _fp]),
+    "swg_attr_decode": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp]),
+    "swg_attr_encode": (C.c_int, [_i32, _i32, _i32, _i32, _i32, _i32, _i32, _fp, _fp, _fp, _fp]),
+    "swg_graph_stats_workspace_bytes": (_sz, [_i32, _i32]),
+    "swg_graph_hists": (C.c_int, [_i32, _i32, _i32, _fp, _fp, _fp, _fp, C.c_double, _fp, _sz, _fp]),
+    "swg_hist_pmf": (C.c_int, [_i32, _i32, _i32, _fp, C.c_double, C.c_double, C.c_double, _fp, _fp]),
+    "swg_mmd_gaussian_tv": (C.c_int, [_i32, _i32, _i32, _fp, _fp, C.c_double, _fp, _fp, _fp]),
     "swg_refresh_derived": (C.c_int, [_fp, _fp, _fp, _fp, _i32, _fp]),
     "swg_prof_enable": (C.c_int, [_i32]),
     "swg_prof_reset": (C.c_int, []),

@@ -116,3 +116,11 @@ NODEADJ_SAMPLER_CASES = {
 # train step of the molecule path (runner/trainer/trainer_node_adj.py:95-126): (case, regime, sigma index, coin)
 NODEADJ_TRAIN_CASES = [("qm9_ddpm60", "init", 0, True), ("qm9_onehot96", "stress", 0, False),
                        ("zinc_ddpm96", "stress", 0, True), ("qm9_ddpm60_nosc", "stress", 0, False)]
+
+
+# attribute codecs (utils/attribute_code.py): number of attribute types k; QM9 has 4 atom / 4 bond types, ZINC 9 / 4
+CODEC_CASES = {
+    "k4": dict(B=5, N=9, k=4, n_lo=3, n_hi=9, seed=91),
+    "k9": dict(B=3, N=20, k=9, n_lo=6, n_hi=20, seed=92),
+    "k2": dict(B=4, N=12, k=2, n_lo=2, n_hi=12, seed=93),
+}
