@@ -67,3 +67,25 @@ def quantise_samples(final_samples, node_flags):
     keep = node_flags.to(torch.bool)
     keep = keep[..., :, None] & keep[..., None, :]
     return ((x > 0) & keep).to(final_samples.dtype)
+
+
+def tile_batch(data_tuple, dataloader):
+    """Batch initialisation of the train loop, runner/trainer/trainer.py:29-47: a 2-tuple gets its node flags from the
+    adjacency (:31); a batch smaller than ``dataloader.batch_size`` that divides it is stacked up to the full batch
+    size, and the stacked tensors are cached on the dataloader (``dataloader.repeated_data``) and returned for every
+    later short batch, exactly as the reference does (small datasets: ego-small, community-small)."""
+    if len(data_tuple) == 2:
+        adjs_gt, x_gt = data_tuple
+        node_flags = adjs_gt.abs().sum(-1).gt(1e-5).to(dtype=torch.float32)
+    elif len(data_tuple) == 3:
+        adjs_gt, x_gt, node_flags = data_tuple
+    else:
+        raise NotImplementedError
+    if len(adjs_gt) < dataloader.batch_size and dataloader.batch_size % len(adjs_gt) == 0:
+        cached = getattr(dataloader, "repeated_data", None)
+        if cached is None:
+            rep = dataloader.batch_size // len(adjs_gt)
+            cached = [adjs_gt.repeat(rep, 1, 1), x_gt.repeat(rep, 1, 1), node_flags.repeat(rep, 1)]
+            dataloader.repeated_data = cached
+        adjs_gt, x_gt, node_flags = cached
+    return adjs_gt, x_gt, node_flags

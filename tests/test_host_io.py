@@ -56,3 +56,30 @@ def test_load_model_reconciles_module_prefix(golden_meta):
     io.load_model(plain, make(), "model_ema_beta_0.9999")
     with pytest.raises(AssertionError):
         io.load_model(plain, dst, "model")
+
+
+def test_tile_batch_matches_trainer_rule():
+    """runner/trainer/trainer.py:29-47: short batches are stacked to batch_size and cached on the dataloader."""
+    from swingnn_amd import io
+
+    class DL:
+        batch_size = 12
+
+    dl = DL()
+    adjs = torch.arange(4 * 5 * 5, dtype=torch.float32).reshape(4, 5, 5)
+    adjs[1] = 0                                                   # an empty graph: all flags 0
+    x = torch.zeros(4, 5, 1)
+    a, xx, f = io.tile_batch((adjs, x), dl)
+    assert a.shape == (12, 5, 5) and xx.shape == (12, 5, 1) and f.shape == (12, 5)
+    assert torch.equal(a, adjs.repeat(3, 1, 1)) and torch.equal(f[:4], adjs.abs().sum(-1).gt(1e-5).float())
+    assert f[1].sum() == 0 and dl.repeated_data[0] is a
+    # the cache wins for every later short batch (the reference's behaviour, even for different data)
+    other = torch.ones(4, 5, 5)
+    a2, _, f2 = io.tile_batch((other, x, torch.ones(4, 5)), dl)
+    assert a2 is a and f2 is f
+    # full batches and non-dividing sizes pass through untouched
+    dl2 = DL()
+    full = torch.ones(12, 5, 5)
+    assert io.tile_batch((full, torch.zeros(12, 5, 1), torch.ones(12, 5)), dl2)[0] is full
+    odd = torch.ones(5, 5, 5)
+    assert io.tile_batch((odd, torch.zeros(5, 5, 1), torch.ones(5, 5)), dl2)[0] is odd and not hasattr(dl2, "repeated_data")
