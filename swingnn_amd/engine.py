@@ -35,10 +35,16 @@ _WS = {}
 
 
 def workspace(device, nbytes: int) -> torch.Tensor:
-    """Scratch buffer from torch's caching allocator, reused across calls on one device."""
-    key = (device.index if device.index is not None else torch.cuda.current_device())
+    """Scratch buffer from torch's caching allocator, one per (device, stream): passes issued on different streams
+    (a sampler on a side stream next to training, the two half-batch streams of network_pass) never share scratch.  A
+    buffer that is outgrown is handed back to the allocator only after the work queued on its stream (record_stream)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    stream = torch.cuda.current_stream(idx)
+    key = (idx, stream.cuda_stream)
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
+        if buf is not None:
+            buf.record_stream(stream)
         buf = torch.empty(max(nbytes, 1 << 20), dtype=torch.uint8, device=device)
         _WS[key] = buf
     return buf
@@ -459,6 +465,33 @@ def _as_f32(t: torch.Tensor) -> torch.Tensor:
 
 PASS_COUNT = 0  # network passes launched through network_pass (reported by bench.py)
 
+# A pass over a large batch is issued as SPLIT_STREAMS independent part-batches on side streams (graphs are independent;
+# every kernel treats samples independently, so the results are bit-identical).  Within one stream kernel k+1 cannot
+# start before the last workgroup of kernel k has drained (tile quantisation: e.g. 448 workgroups on 256 CUs leave a
+# quarter of the second round idle); with two streams in flight the tail of one part's kernel overlaps the body of the
+# other part's.  Measured on grid dim-96, B = 112: 7.57 -> 7.04 ms per pass (scripts/exp_two_streams.py); four parts are
+# slower (more, smaller launches).  Off for small problems (launch-bound), under stream capture and while the
+# library's per-kernel profiler is on (overlapped kernels would be timed against each other).
+SPLIT_STREAMS = 2
+SPLIT_MIN_WORK = 8_000_000   # B * N * N below which a pass stays on one stream
+_SIDE = {}
+_PROFILING = False           # set by prof.profiled()
+
+
+def _side_streams(idx: int, n: int):
+    key = (idx, n)
+    st = _SIDE.get(key)
+    if st is None:
+        st = _SIDE[key] = [torch.cuda.Stream(device=idx) for _ in range(n)]
+    return st
+
+
+def _launch_pass(cache, B, mode, x, flags, labels, labels_uniform, sc, out, sym_err):
+    ws = workspace(x.device, cache.ws_bytes(B))
+    L.check(L.lib.swg_precond_forward(C.byref(cache.net), B, mode, x.data_ptr(), flags.data_ptr(), labels.data_ptr(),
+                                      int(labels_uniform), _ptr(sc), out.data_ptr(), _ptr(sym_err), ws.data_ptr(),
+                                      ws.numel(), stream_ptr()), "swg_precond_forward")
+
 
 def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_uniform: bool, self_cond, out=None,
                  sym_err=None):
@@ -474,11 +507,25 @@ def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
         raise AssertionError(f"Input image size ({x.shape[-2]}*{N}) doesn't match model ({cache.net.N}*{cache.net.N}).")
     if out is None:
         out = torch.empty_like(x)
-    nbytes = cache.ws_bytes(B)
-    ws = workspace(x.device, nbytes)
-    L.check(L.lib.swg_precond_forward(C.byref(cache.net), B, mode, x.data_ptr(), flags.data_ptr(), labels.data_ptr(),
-                                      int(labels_uniform), _ptr(sc), out.data_ptr(), _ptr(sym_err), ws.data_ptr(),
-                                      ws.numel(), stream_ptr()), "swg_precond_forward")
+    parts = SPLIT_STREAMS
+    if (parts < 2 or _PROFILING or B % parts or B * N * N < SPLIT_MIN_WORK
+            or torch.cuda.is_current_stream_capturing()):
+        _launch_pass(cache, B, mode, x, flags, labels, labels_uniform, sc, out, sym_err)
+        return out
+    dev_idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+    cur = torch.cuda.current_stream(dev_idx)
+    fork = torch.cuda.Event()
+    fork.record(cur)
+    h = B // parts
+    for i, side in enumerate(_side_streams(dev_idx, parts)):
+        lo, hi = i * h, (i + 1) * h
+        side.wait_event(fork)
+        with torch.cuda.stream(side):
+            _launch_pass(cache, h, mode, x[lo:hi], flags[lo:hi], labels if labels_uniform else labels[lo:hi],
+                         labels_uniform, None if sc is None else sc[lo:hi], out[lo:hi], sym_err)
+        join = torch.cuda.Event()
+        join.record(side)
+        cur.wait_event(join)   # later work on the caller's stream (and frees of x / out) is ordered after the parts
     return out
 
 

@@ -18,9 +18,14 @@ def read():
 
 @contextmanager
 def profiled():
+    """Per-kernel timing: passes stay on ONE stream meanwhile (engine.network_pass would otherwise overlap the kernels of
+    two part-batches, and each would be timed against the other)."""
+    from . import engine
     L.lib.swg_prof_reset()
     L.lib.swg_prof_enable(1)
+    engine._PROFILING = True
     try:
         yield
     finally:
+        engine._PROFILING = False
         L.lib.swg_prof_enable(0)

@@ -387,6 +387,34 @@ def test_pass_reuse_is_bit_identical(S, golden_meta):
         print(f"{net_name}: {counts[0]} passes by default, {counts[1]} with reuse ({steps} Heun steps)")
 
 
+def test_split_stream_pass_is_bit_identical(S, golden_meta, monkeypatch):
+    """engine.network_pass issues a large batch as two part-batches on two streams: same bits as one launch, the
+    symmetry accumulator still sees every sample, and the caller's stream is ordered after both parts."""
+    from swingnn_amd import engine as E
+    pre = build_precond(S, "grid192", golden_meta, "init")
+    c = NET_CASES["grid192"]
+    B, N = 6, c["cfg"]["img_size"]
+    flags = filler.node_flags("flags", B, N, c["n_lo"], c["n_hi"], 3).to(DEV)
+    x = filler.sym_adj("x", B, N, flags.cpu(), 3, 2.0).to(DEV)
+    sig = torch.full((1,), 1.7, device=DEV).expand(B)
+    outs = []
+    for parts, min_work in ((0, 0), (2, 0), (3, 0)):
+        monkeypatch.setattr(E, "SPLIT_STREAMS", parts)
+        monkeypatch.setattr(E, "SPLIT_MIN_WORK", min_work)
+        for u in (0.25, 0.75):                       # with and without the self-conditioning pre-pass
+            monkeypatch.setattr(np.random, "rand", lambda u=u: u)
+            outs.append(pre(x, flags, sig).clone())
+        pre.assert_symmetric()
+    for k in (2, 4):
+        assert torch.equal(outs[0], outs[k]) and torch.equal(outs[1], outs[k + 1])
+    per_sample = torch.linspace(0.5, 3.0, B, device=DEV)
+    monkeypatch.setattr(E, "SPLIT_STREAMS", 0)
+    a = pre(x, flags, per_sample)
+    monkeypatch.setattr(E, "SPLIT_STREAMS", 2)
+    b = pre(x, flags, per_sample)
+    assert torch.equal(a, b)
+
+
 # ---------------------------------------------------------------------------------------------
 def test_objective_and_loss(S, golden):
     """Rows a18/a19: training objective (noisy input, sigmas, weights, preconditioning scalars) and loss, forward."""
