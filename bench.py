@@ -120,10 +120,13 @@ def whole_job_value(batch_per_rank, world, steps, dt_max):
     return batch_per_rank * world * steps / dt_max
 
 
-def roofline_objects(kern, batch, config):
+def roofline_objects(kern, batch, config, launch_batch=None):
     """`roofline` (ONE kernel symbol: the one with the largest share of GPU time) and `window_attn` (the fused
     window-attention kernel of every stage against the dense bf16 MFMA peak) from the library profiler's tallies
-    {symbol: dict(ms, flops, bytes, launches)}.  Formulas: DESIGN.md section 4."""
+    {symbol: dict(ms, flops, bytes, launches)}.  `launch_batch`: graphs per kernel launch (the part-batch when the pass
+    is split over two streams, engine.launch_batch); all per-launch figures are for that many graphs.  Formulas:
+    DESIGN.md section 4."""
+    launch_batch = batch if launch_batch is None else launch_batch
     total_ms = sum(k["ms"] for k in kern.values())
     name, dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
     avg_s = dom["ms"] * 1e-3 / dom["launches"]
@@ -142,11 +145,11 @@ def roofline_objects(kern, batch, config):
         import glob
         for path in sorted(glob.glob(os.path.join(ROOT, "profiles", "*pmc_traffic.json")), reverse=True):
             prof_json = json.load(open(path))
-            if prof_json.get("batch", 56) == batch and name in prof_json["kernels"]:
+            if prof_json.get("launch_batch", prof_json.get("batch", 56)) == launch_batch and name in prof_json["kernels"]:
                 traffic = prof_json["kernels"][name]["hbm_bytes_per_launch"]
                 traffic_src = os.path.relpath(path, ROOT) + ": " + prof_json["method"]
                 break
-    roof.update(kernel=name, traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
+    roof.update(kernel=name, graphs_per_launch=launch_batch, traffic=traffic, traffic_unit="bytes/launch", traffic_source=traffic_src,
                 algorithmic_bytes_per_launch=dom["bytes"] / dom["launches"],
                 algorithmic_flops_per_launch=dom["flops"] / dom["launches"], avg_launch_us=avg_s * 1e6,
                 launches=dom["launches"], share_of_gpu_time=dom["ms"] / total_ms,
@@ -154,7 +157,8 @@ def roofline_objects(kern, batch, config):
                 kernels={k: dict(ms=round(v["ms"], 3), launches=v["launches"],
                                  tflops=round(v["flops"] / (v["ms"] * 1e-3) / 1e12, 2),
                                  GBs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in kern.items()},
-                sample="4-step sample() replay, same batch, profiler on (untimed)")
+                sample="4-step sample() replay, same batch and the same (part-batch) launches, issued on one stream, "
+                       "profiler on (untimed)")
     stages = {"s0_C96": "k_wattn_res", "s1_C192": "k_wattn_ring<192>", "s2_C384": "k_wattn_ring<384>",
               "s3_C768_core_only": "k_wattn_core"}
     wattn = {"peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
@@ -255,7 +259,7 @@ def main():
         with torch.no_grad(), prof.profiled():
             short.sample(model, flags)
         kern = prof.read()
-        roof, wattn = roofline_objects(kern, args.batch, args.config)
+        roof, wattn = roofline_objects(kern, args.batch, args.config, _E.launch_batch(args.batch, cfg["img_size"]))
         result = {
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.config == "grid"
             else f"sampled graphs/sec, EDM {args.config}",

@@ -34,6 +34,11 @@ def load(dirname, counter):
 
 d, out = sys.argv[1], sys.argv[2]
 batch = int(sys.argv[3]) if len(sys.argv) > 3 else 56
+import os
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import bench
+from swingnn_amd import engine
+launch_batch = engine.launch_batch(batch, bench.CONFIGS["grid"]["img_size"])  # graphs per kernel launch (part-batch)
 f, nf = load(d, "FETCH_SIZE")
 w, nw = load(d, "WRITE_SIZE")
 res = {}
@@ -43,7 +48,7 @@ for k in sorted(f, key=lambda k: -(2 * f[k] + w.get(k, 0))):
     n = nf[k]
     res[k] = dict(launches=n, fetch_size_kib_per_launch=f[k] / n, write_size_kib_per_launch=w.get(k, 0.0) / max(nw.get(k, 1), 1),
                   hbm_bytes_per_launch=(2 * f[k] / n + w.get(k, 0.0) / max(nw.get(k, 1), 1)) * 1024)
-json.dump(dict(batch=batch, method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/prof_forward.py; "
+json.dump(dict(batch=batch, launch_batch=launch_batch, method="rocprofv3 --pmc FETCH_SIZE / --pmc WRITE_SIZE (separate passes) over scripts/prof_forward.py; "
                       "hbm_bytes = (2*FETCH_SIZE + WRITE_SIZE)*1024 (gfx950 read-side correction)", kernels=res),
           open(out, "w"), indent=1)
 for k, v in res.items():

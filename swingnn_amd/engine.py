@@ -470,12 +470,19 @@ PASS_COUNT = 0  # network passes launched through network_pass (reported by benc
 # start before the last workgroup of kernel k has drained (tile quantisation: e.g. 448 workgroups on 256 CUs leave a
 # quarter of the second round idle); with two streams in flight the tail of one part's kernel overlaps the body of the
 # other part's.  Measured on grid dim-96, B = 112: 7.57 -> 7.04 ms per pass (scripts/exp_two_streams.py); four parts are
-# slower (more, smaller launches).  Off for small problems (launch-bound), under stream capture and while the
-# library's per-kernel profiler is on (overlapped kernels would be timed against each other).
+# slower (more, smaller launches).  Off for small problems (launch-bound) and under stream capture.  While the
+# library's per-kernel profiler is on, the SAME part-batch launches are issued one after the other on the caller's
+# stream (overlapped kernels would be timed against each other): what is timed is what the product path launches.
 SPLIT_STREAMS = 2
 SPLIT_MIN_WORK = 8_000_000   # B * N * N below which a pass stays on one stream
 _SIDE = {}
 _PROFILING = False           # set by prof.profiled()
+
+
+def launch_batch(B: int, N: int) -> int:
+    """Graphs per kernel launch of a pass over B graphs of N nodes (the part-batch when the pass is split)."""
+    parts = SPLIT_STREAMS
+    return B if (parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK) else B // parts
 
 
 def _side_streams(idx: int, n: int):
@@ -508,15 +515,20 @@ def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
     if out is None:
         out = torch.empty_like(x)
     parts = SPLIT_STREAMS
-    if (parts < 2 or _PROFILING or B % parts or B * N * N < SPLIT_MIN_WORK
-            or torch.cuda.is_current_stream_capturing()):
+    if (parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK or torch.cuda.is_current_stream_capturing()):
         _launch_pass(cache, B, mode, x, flags, labels, labels_uniform, sc, out, sym_err)
+        return out
+    h = B // parts
+    if _PROFILING:
+        for lo in range(0, B, h):
+            hi = lo + h
+            _launch_pass(cache, h, mode, x[lo:hi], flags[lo:hi], labels if labels_uniform else labels[lo:hi],
+                         labels_uniform, None if sc is None else sc[lo:hi], out[lo:hi], sym_err)
         return out
     dev_idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
     cur = torch.cuda.current_stream(dev_idx)
     fork = torch.cuda.Event()
     fork.record(cur)
-    h = B // parts
     for i, side in enumerate(_side_streams(dev_idx, parts)):
         lo, hi = i * h, (i + 1) * h
         side.wait_event(fork)

@@ -18,8 +18,9 @@ def read():
 
 @contextmanager
 def profiled():
-    """Per-kernel timing: passes stay on ONE stream meanwhile (engine.network_pass would otherwise overlap the kernels of
-    two part-batches, and each would be timed against the other)."""
+    """Per-kernel timing: the part-batches of a split pass are issued one after the other on ONE stream meanwhile
+    (engine.network_pass would otherwise overlap the kernels of two part-batches, and each would be timed against the
+    other); the launches themselves are those of the product path."""
     from . import engine
     L.lib.swg_prof_reset()
     L.lib.swg_prof_enable(1)
