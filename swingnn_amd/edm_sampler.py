@@ -108,7 +108,9 @@ class EDMSampler(GeneralSampler):
     def sample(self, model, node_flags, init_adjs=None, sanity_check_gt_adjs=None,
                flag_interim_adjs=False, max_num_interim_adjs=None, flag_use_double=False):
         if flag_use_double:
-            raise NotImplementedError("swingnn_amd.EDMSampler keeps the Heun state in float32")
+            raise NotImplementedError(
+                "flag_use_double: the Heun state is float32 here.  (In the reference the float64 x_hat reaches the "
+                "float32 network un-cast, edm.py:183 / precond.py:30-49, and torch raises a dtype RuntimeError too.)")
         inner = model.module if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else model
         if init_adjs is None:
             init_adjs = self.gen_init_sample(node_flags, folded_norm=True)
@@ -231,7 +233,9 @@ class NodeAdjEDMSampler(EDMSampler):
                sanity_check_gt_nodes=None, flag_interim_adjs=False, max_num_interim_adjs=None, flag_use_double=False,
                flag_node_multi_channel=False, flag_adj_multi_channel=False, num_node_chan=150, num_edge_chan=51):
         if flag_use_double:
-            raise NotImplementedError("swingnn_amd.NodeAdjEDMSampler keeps the Heun state in float32")
+            raise NotImplementedError(
+                "flag_use_double: the Heun state is float32 here.  (In the reference the float64 state reaches the "
+                "float32 network un-cast, edm.py:366 / precond.py:80-103, and torch raises a dtype RuntimeError too.)")
         inner = model.module if isinstance(model, (nn.DataParallel, nn.parallel.DistributedDataParallel)) else model
         if init_adjs is None or init_nodes is None:
             init_adjs, init_nodes = self.gen_init_sample(node_flags, folded_norm=False, num_node_chan=num_node_chan,
