@@ -6,6 +6,7 @@ the C descriptor structs (include/swingnn_hip.h).  It is rebuilt whenever a para
 counter, storage or device changes.  PyTorch is used only for device memory and streams.
 """
 import ctypes as C
+import os
 
 import torch
 
@@ -473,7 +474,7 @@ PASS_COUNT = 0  # network passes launched through network_pass (reported by benc
 # slower (more, smaller launches).  Off for small problems (launch-bound) and under stream capture.  While the
 # library's per-kernel profiler is on, the SAME part-batch launches are issued one after the other on the caller's
 # stream (overlapped kernels would be timed against each other): what is timed is what the product path launches.
-SPLIT_STREAMS = 2
+SPLIT_STREAMS = int(os.environ.get("SWG_SPLIT_STREAMS", "2"))   # tuning knob for scripts/, not an API
 SPLIT_MIN_WORK = 8_000_000   # B * N * N below which a pass stays on one stream
 _SIDE = {}
 _PROFILING = False           # set by prof.profiled()

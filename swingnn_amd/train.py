@@ -128,6 +128,43 @@ class GradBook:
         return self.views[name].data_ptr()
 
 
+class _Readiness:
+    """Which tail of the flat gradient buffer is complete, derived from the modules whose backward has been enqueued
+    (not from an assumed registration order): `flat[lo:]` is handed to the gradient sync only when EVERY parameter at
+    or after `lo` belongs to a finished module.  `assert_complete` fails loudly for a model layout with a parameter no
+    backward call owns."""
+
+    def __init__(self, book, sync, model):
+        self.sync = sync
+        index = getattr(model, "_swg_ready_index", None)
+        if index is None or index[0] != len(book.offset):  # static per model: built once
+            entries = sorted((o, name) for name, o in book.offset.items())
+            by_prefix = {}
+            for i, (_, name) in enumerate(entries):
+                parts = name.split(".")
+                for d in range(1, len(parts) + 1):
+                    by_prefix.setdefault(".".join(parts[:d]), []).append(i)
+            index = model._swg_ready_index = (len(entries), entries, by_prefix)
+        _, self.entries, self.by_prefix = index
+        self.done = [False] * len(self.entries)
+        self.tail = len(self.entries)  # entries[tail:] are all done
+
+    def finish(self, *prefixes):
+        for p in prefixes:
+            for i in self.by_prefix.get(p, ()):
+                self.done[i] = True
+        moved = False
+        while self.tail > 0 and self.done[self.tail - 1]:
+            self.tail -= 1
+            moved = True
+        if moved and self.sync is not None:
+            self.sync.ready_from(self.entries[self.tail][0])
+
+    def assert_complete(self):
+        missing = [name for (_, name), d in zip(self.entries, self.done) if not d]
+        assert not missing, f"no backward call produced the gradient of {missing[:4]} (+{max(0, len(missing) - 4)} more)"
+
+
 def _lin_train(tc, book, prefix, bias=True):
     return L.SwgLinTrain(tc.wt[prefix + ".weight"].data_ptr(), book.ptr(prefix + ".weight"),
                          book.ptr(prefix + ".bias") if bias else None)
@@ -263,7 +300,7 @@ def _readout_chain_grads(model, p, dweff, dbeff):
     return dict(zip([id(t) for t in leaves], [g.float() for g in grads]))
 
 
-def _trunk_backward(cache, tc, book, names, saved, dcur, cond, ct, dcond, B, wp, wn, st, sync, first_of):
+def _trunk_backward(cache, tc, book, names, saved, dcur, cond, ct, dcond, B, wp, wn, st, ready):
     """Backward through the encoder / decoder layers: gradient of the final tokens -> gradient of the embedded tokens;
     parameter gradients accumulate into `book`, conditioning gradients into `dcond`."""
     dskips = {}
@@ -306,8 +343,7 @@ def _trunk_backward(cache, tc, book, names, saved, dcur, cond, ct, dcond, B, wp,
                  dcur.data_ptr(), dx.data_ptr(), dskip.data_ptr(), wp, wn, st)
             dskips[si] = dskip
             dcur = dx
-        if sync is not None:  # this module and everything after it in parameter order is complete
-            sync.ready_from(first_of[pre])
+        ready.finish(pre)  # the kernels that write this module's gradients are enqueued
     return dcur
 
 
@@ -329,10 +365,9 @@ def backward_all(model, state, dD):
     names = _layer_names(model)
     if sync is not None:
         sync.begin(book.flat)
-    first_of = {}  # flat offset of the first parameter of every module prefix (modules own contiguous slices)
-    for pname, o in book.offset.items():
-        for depth in (2, 3, 4):
-            first_of.setdefault(".".join(pname.split(".")[:depth]), o)
+    ready = _Readiness(book, sync, model)
+    # flat slots of the parameters whose gradient comes from the parameter-sized torch chain rules below stay unused
+    ready.finish("map_layer0", "map_layer1", "read_out")
     ct = net.cond_total
     cond = state["cond"]
     p = net.p
@@ -345,11 +380,14 @@ def backward_all(model, state, dD):
     dcur = torch.empty_like(tok_final)
     _run(L.lib.swg_readout_sym_precond_bwd, "swg_readout_sym_precond_bwd", _c(net), _c(ends), B, tok_final.data_ptr(),
          state["flags"].data_ptr(), state["coef"].data_ptr(), dD.data_ptr(), dcur.data_ptr(), wp, wn, st)
+    ready.finish("norm")
     dcond = torch.zeros((B, ct), **f32)
-    dcur = _trunk_backward(cache, tc, book, names, state["saved"], dcur, cond, ct, dcond, B, wp, wn, st, sync, first_of)
+    dcur = _trunk_backward(cache, tc, book, names, state["saved"], dcur, cond, ct, dcond, B, wp, wn, st, ready)
     _run(L.lib.swg_patch_embed_bwd, "swg_patch_embed_bwd", _c(net), _c(ends), B, state["x"].data_ptr(),
          E._ptr(state["sc"]), state["coef"].data_ptr() + 8, 4, cond.data_ptr(), ct, dcur.data_ptr(), dcond.data_ptr(), ct,
          wp, wn, st)
+    ready.finish("patch_embed")
+    ready.assert_complete()
     out = {id(prm): book.views[name] for name, prm in model.named_parameters()}
     small = _cond_chain_grads(model, state["cnoise"], dcond)
     small.update(_readout_chain_grads(model, p, dro_w, dro_b[:p * p].sum()))
@@ -456,10 +494,8 @@ def backward_all_nodeadj(model, state, dDa, dDn):
     names = _layer_names(model)
     if sync is not None:
         sync.begin(book.flat)
-    first_of = {}
-    for pname, o in book.offset.items():
-        for depth in (2, 3, 4):
-            first_of.setdefault(".".join(pname.split(".")[:depth]), o)
+    ready = _Readiness(book, sync, model)
+    ready.finish("map_layer0", "map_layer1", "read_out")
     ct = net.cond_total
     cond = state["cond"]
     p, C0 = net.p, net.C0
@@ -476,13 +512,16 @@ def backward_all_nodeadj(model, state, dDa, dDn):
     _run(L.lib.swg_nodeadj_readout_bwd, "swg_nodeadj_readout_bwd", _c(net), _c(na), _c(tr), B, tok_final.data_ptr(),
          state["flags"].data_ptr(), state["coef"].data_ptr() if state["mode"] else None, dDa.data_ptr(), dDn.data_ptr(),
          dcur.data_ptr(), wp, wn, st)
+    ready.finish("norm", "readout_adj_mlp", "readout_node_mlp")
     dcond = torch.zeros((B, ct), **f32)
-    dcur = _trunk_backward(cache, tc, book, names, state["saved"], dcur, cond, ct, dcond, B, wp, wn, st, sync, first_of)
+    dcur = _trunk_backward(cache, tc, book, names, state["saved"], dcur, cond, ct, dcond, B, wp, wn, st, ready)
     ends = L.SwgEndsTrain(tc.pe_wb.data_ptr(), book.ptr("patch_embed.proj.weight"), book.ptr("patch_embed.proj.bias"),
                           _ln_train(book, "patch_embed.norm"), _ln_train(book, "norm"), None, None, None)
     _run(L.lib.swg_nodeadj_embed_bwd, "swg_nodeadj_embed_bwd", _c(net), _c(na), _c(ends), B, state["adj"].data_ptr(),
          state["node"].data_ptr(), E._ptr(state["sc_adj"]), E._ptr(state["sc_node"]), state["flags"].data_ptr(),
          state["coef"].data_ptr() + 8, 4, cond.data_ptr(), ct, dcur.data_ptr(), dcond.data_ptr(), ct, wp, wn, st)
+    ready.finish("patch_embed")
+    ready.assert_complete()
     out = {id(prm): book.views[name] for name, prm in model.named_parameters()}
     small = _cond_chain_grads(model, state["cnoise"], dcond)
     dweff = dro_w.view(p * p, Cp, C0)[:, :C0, :]

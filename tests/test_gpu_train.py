@@ -267,3 +267,55 @@ def test_train_step_gradients_odd_windows(win, img):
         if rel > 3e-2:
             bad.append((k, rel))
     assert not bad, bad
+
+
+@pytest.mark.parametrize("name", ["grid192", "com96"])
+def test_gradient_sync_sends_only_finished_slices(golden_meta, name, monkeypatch):
+    """The backward hands flat[lo:] to the gradient sync while later kernels still run (parallel.GradSync).  A stand-in
+    for a 2-rank group with identical ranks DOUBLES every slice at the moment it is sent (the loss gradient is
+    pre-scaled by 1 / world_size = 1/2, powers of two: exact): the result equals the unsynced gradients only if no
+    slice is sent before every kernel that accumulates into it has been enqueued (train._Readiness)."""
+    import swingnn_amd as S
+    from swingnn_amd.parallel import GradSync
+    from tests.test_gpu_parity import build_precond
+    c = NET_CASES[name]
+    flags, x, sig, w, clean = (t.to(DEV) for t in H.train_case_inputs(c, 1))
+    loss_fn = S.RainbowLoss(1.0, False, "edm")
+    monkeypatch.setattr(np.random, "rand", lambda: 0.25)
+
+    class DoublingSync(GradSync):
+        world_size = 2
+
+        def __init__(self, bucket_bytes):
+            super().__init__(None, bucket_bytes)
+            self.sent = []
+
+        def _send(self, lo):
+            if lo < self.sent_lo:
+                self.flat[lo:self.sent_lo].mul_(2.0)
+                self.sent.append((lo, self.sent_lo))
+                self.sent_lo = lo
+
+        def finish(self, extra=()):
+            self._send(0)
+            extra = [t for t in extra if t is not None]
+            for t in extra:
+                t.mul_(2.0)
+            return extra
+
+    def grads(sync):
+        pre = build_precond(S, name, golden_meta, "init").train()
+        pre.model._swg_grad_sync = sync
+        with torch.enable_grad():
+            D = pre(x=x, node_flags=flags, sigmas=sig)
+            loss_fn(D, clean, sig, x, clean, flags, loss_weight=w, reduction='none').mean().backward()
+        return {k: p.grad.detach().clone() for k, p in pre.named_parameters()}
+
+    plain = grads(None)
+    sync = DoublingSync(bucket_bytes=16 << 10)
+    synced = grads(sync)
+    assert len(sync.sent) >= 4, sync.sent            # the buffer really went out in pieces, tail first
+    assert all(later[1] == earlier[0] for later, earlier in zip(sync.sent[1:], sync.sent[:-1])) and sync.sent[-1][0] == 0, sync.sent
+    for k, g in plain.items():
+        scale = float(g.abs().max()) + 1e-30
+        assert float((synced[k] - g).abs().max()) <= 1e-5 * scale, k
