@@ -70,7 +70,8 @@ int check_lin_train(const swg_lin_train& t, bool bias) {
 int wattn_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const float* x_in, const float* cond,
                    int cond_stride, const float* dy, float* dx, float* dcond, int dcond_stride, Carver& cv, hipStream_t s) {
   const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C), ldq = ldq_of(C), Q3p = kp(3 * C);
-  float* x1 = cv.take<float>((size_t)T * C);
+  const bool fused_tail = ln_cond_bwd_supported(C);
+  float* x1 = fused_tail ? nullptr : cv.take<float>((size_t)T * C);
   bf16* xn = cv.take<bf16>((size_t)T * Cp);
   bf16* qkv = cv.take<bf16>((size_t)T * ldq);
   bf16* o = cv.take<bf16>((size_t)T * Cp);
@@ -78,7 +79,7 @@ int wattn_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const
   bf16* dO = cv.take<bf16>((size_t)T * Cp);
   bf16* dqkv = cv.take<bf16>((size_t)T * Q3p);
   float* dxn = cv.take<float>((size_t)T * C);
-  float* dxc = cv.take<float>((size_t)T * C);
+  float* dxc = fused_tail ? nullptr : cv.take<float>((size_t)T * C);
   WgradScratch w = take_wgrad(cv, 3 * C, C, T);
   if (cv.measure) return 0;
   if (!cv.ok) return SWG_E_WORKSPACE;
@@ -107,7 +108,11 @@ int wattn_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const
   if ((r = launch_gemm(dqkv, Q3p, (const bf16*)tr->qkv.wt, T, C, Q3p, e2, s))) return r;
   if ((r = wgrad_tn(dqkv, Q3p, 3 * C, xn, Cp, C, T, tr->qkv.dw, w, s))) return r;
   if ((r = launch_colsum_bf16(dqkv, T, 3 * C, Q3p, tr->qkv.db, s))) return r;
-  // ---- LN1 + shortcut (:241-244, :272): dxc = dy + d LN1 ----
+  // ---- LN1 + shortcut (:241-244, :272) and conditioning (:238-240) in one pass; the shortcut x1 is recomputed ----
+  if (fused_tail)
+    return launch_ln_cond_bwd(x_in, dxn, dy, blk->ln1.g, cond, cond_stride, blk->cond_off, B, L, C, dx, tr->ln1.dg,
+                              tr->ln1.db, dcond, dcond_stride, s);
+  // ---- LN1 + shortcut: dxc = dy + d LN1 ----
   if ((r = launch_ln_bwd(x1, dxn, blk->ln1.g, dy, T, C, dxc, tr->ln1.dg, tr->ln1.db, s))) return r;
   // ---- conditioning (:238-240) ----
   return launch_cond_bwd(x_in, dxc, cond, cond_stride, blk->cond_off, B, L, C, dx, dcond, dcond_stride, s);
@@ -133,15 +138,15 @@ int mlp_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const f
   GemmEpi e = {};
   e.bias = blk->fc1.b; e.out_bf16 = h; e.ldo = Hp; e.n_store = Hp;
   if ((r = launch_gemm(xn, Cp, (const bf16*)blk->fc1.w, T, H, Cp, e, s))) return r;
-  if ((r = launch_gelu_fwd(h, a, (size_t)T * Hp, s))) return r;
-  // ---- fc2 ----
+  // ---- fc2: da = dy W2 ----
   if ((r = launch_cast_pad_colsum(dy, T, C, C, dyb, Cp, tr->fc2.db, s))) return r;
   GemmEpi e1 = {};
   e1.out_bf16 = da; e1.ldo = Hp; e1.n_store = Hp;
   if ((r = launch_gemm(dyb, Cp, (const bf16*)tr->fc2.wt, T, H, Cp, e1, s))) return r;
+  // ---- GELU: one pass over h gives the activation a = gelu(h) (operand of dW2) and dh = da gelu'(h) (+ db1) ----
+  if ((r = launch_gelu_bwd_colsum(h, da, da, a, T, H, Hp, tr->fc1.db, s))) return r;
   if ((r = wgrad_tn(dyb, Cp, C, a, Hp, H, T, tr->fc2.dw, w, s))) return r;
-  // ---- GELU, fc1 ----
-  if ((r = launch_gelu_bwd_colsum(h, da, da, T, H, Hp, tr->fc1.db, s))) return r;
+  // ---- fc1 ----
   GemmEpi e2 = {};
   e2.out_f32 = dxn; e2.ldo = C;
   if ((r = launch_gemm(da, Hp, (const bf16*)tr->fc1.wt, T, C, Hp, e2, s))) return r;
@@ -321,7 +326,7 @@ int na_head_bwd(const swg_lin& fc1, const swg_lin_train& t1, const float* w2, fl
   if ((r = wgrad(dy, nullptr, Co, Co, act, Cp, C0, rows, dw2, w, s))) return r;
   if ((r = launch_colsum_f32(dy, rows, Co, Co, db2, s))) return r;
   if ((r = launch_na_head_bwd(dy, w2, rows, C0, Co, act, Cp, s))) return r;   // act now holds d(act)
-  if ((r = launch_gelu_bwd_colsum(pre, act, act, rows, C0, Cp, t1.db, s))) return r;   // ... and now d(pre); db1 too
+  if ((r = launch_gelu_bwd_colsum(pre, act, act, nullptr, rows, C0, Cp, t1.db, s))) return r;   // ... and now d(pre); db1 too
   GemmEpi e2 = {};
   e2.out_f32 = din; e2.ldo = C0;
   if (accumulate) { e2.residual = din; e2.ldr = C0; }

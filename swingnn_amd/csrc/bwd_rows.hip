@@ -123,9 +123,10 @@ __global__ __launch_bounds__(256) void k_cast_pad_colsum(const float* __restrict
   }
 }
 // GELU backward: dh = da gelu'(h) (bf16 [rows, ld], in place allowed), db[c] += sum_rows dh for c < N
+// a_out (optional): the activation a = gelu(h) itself, for the fc2 weight gradient -- one read of h serves both
 __global__ __launch_bounds__(256) void k_gelu_bwd_colsum(const bf16* __restrict__ h, const bf16* __restrict__ da,
-                                                         bf16* __restrict__ dh, int rows, int N, int ld, int rpb,
-                                                         float* __restrict__ db) {
+                                                         bf16* __restrict__ dh, bf16* __restrict__ a_out, int rows, int N,
+                                                         int ld, int rpb, float* __restrict__ db) {
   __shared__ float part[16][129];
   const int cx = threadIdx.x & 15, ry = threadIdx.x >> 4;
   const int c = (blockIdx.x * 16 + cx) * 8;
@@ -138,12 +139,16 @@ __global__ __launch_bounds__(256) void k_gelu_bwd_colsum(const bf16* __restrict_
       const size_t o = (size_t)r * ld + c;
       const bf16x8 v = *reinterpret_cast<const bf16x8*>(h + o);
       const bf16x8 g = *reinterpret_cast<const bf16x8*>(da + o);
-      bf16x8 w;
+      bf16x8 w, av;
 #pragma unroll
       for (int j = 0; j < 8; ++j) {
-        w[j] = (bf16)((float)g[j] * gelu_grad((float)v[j]));
+        const float x = (float)v[j];
+        const float cdf = 0.5f * (1.0f + erff(x * kInvSqrt2));  // gelu = x cdf, gelu' = cdf + x pdf
+        av[j] = (bf16)(x * cdf);
+        w[j] = (bf16)((float)g[j] * (cdf + x * kInvSqrt2Pi * __expf(-0.5f * x * x)));
         acc[j] += (float)w[j];
       }
+      if (a_out) *reinterpret_cast<bf16x8*>(a_out + o) = av;
       *reinterpret_cast<bf16x8*>(dh + o) = w;
     }
   }
@@ -306,6 +311,141 @@ __global__ __launch_bounds__(256) void k_cond_bwd(const float* __restrict__ x, c
   for (int c = threadIdx.x; c < C; c += 256) {
     atomicAdd(drow + c, red[c]);
     atomicAdd(drow + C + c, red[C + c]);
+  }
+}
+
+// ---- LayerNorm1 backward + conditioning backward of a block's attention half in ONE pass over the rows
+// (swin_gnn.py:238-244, :272):  z = shift + x (1 + scale), x1 = silu(z), xn = LN1(x1);  given dxn and the shortcut
+// gradient dres:  dx1 = dres + LN1'(dxn),  dz = dx1 silu'(z),  dx = dz (1 + scale),  dscale += sum_t dz x,
+// dshift += sum_t dz,  dg += sum dxn xhat,  db += sum dxn.  x1 is recomputed from the block input: neither x1 nor dx1
+// ever goes to memory.  grid (token chunks, B); a group of LANES lanes per row, V float4 chunks per lane.
+template <int LANES, int V>
+__global__ __launch_bounds__(256) void k_ln_cond_bwd(const float* __restrict__ x, const float* __restrict__ dxn,
+                                                     const float* __restrict__ dres, const float* __restrict__ g,
+                                                     const float* __restrict__ cond, int cond_stride, int cond_off, int C,
+                                                     int L, int tpb, float* __restrict__ dx, float* __restrict__ dg,
+                                                     float* __restrict__ db, float* __restrict__ dcond, int dcond_stride) {
+  extern __shared__ __attribute__((aligned(16))) float red[];  // [4][C]: dg, db, dscale, dshift
+  constexpr int GROUPS = 256 / LANES;
+  const int li = threadIdx.x % LANES, gi = threadIdx.x / LANES;
+  const int b = blockIdx.y;
+  const int t0 = blockIdx.x * tpb, t1 = min(L, t0 + tpb);
+  const float* crow = cond + (size_t)b * cond_stride + cond_off;
+  const int nch = C >> 2;
+  float4 gg[V], sc1[V], sh[V], ag[V], ab[V], asc[V], ash[V];
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = li + LANES * i;
+    const float4 zero = make_float4(0.f, 0.f, 0.f, 0.f);
+    gg[i] = sc1[i] = sh[i] = ag[i] = ab[i] = asc[i] = ash[i] = zero;
+    if (c < nch) {
+      gg[i] = *reinterpret_cast<const float4*>(g + 4 * c);
+      const float4 s4 = *reinterpret_cast<const float4*>(crow + 4 * c);
+      sc1[i] = make_float4(s4.x + 1.f, s4.y + 1.f, s4.z + 1.f, s4.w + 1.f);
+      sh[i] = *reinterpret_cast<const float4*>(crow + C + 4 * c);
+    }
+  }
+  for (int i = threadIdx.x; i < 4 * C; i += 256) red[i] = 0.f;
+  const float invC = 1.0f / (float)C;
+  for (int t = t0 + gi; t < t1; t += GROUPS) {
+    const size_t ro = ((size_t)b * L + t) * C;
+    float xv[V][4], zz[V][4], sg[V][4], xh[V][4], dn[V][4];
+    float s = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = li + LANES * i;
+      float4 xq = make_float4(0.f, 0.f, 0.f, 0.f), dq = xq;
+      if (c < nch) {
+        xq = *reinterpret_cast<const float4*>(x + ro + 4 * c);
+        dq = *reinterpret_cast<const float4*>(dxn + ro + 4 * c);
+      }
+      const float xa[4] = {xq.x, xq.y, xq.z, xq.w}, da[4] = {dq.x, dq.y, dq.z, dq.w};
+      const float sa[4] = {sc1[i].x, sc1[i].y, sc1[i].z, sc1[i].w}, ha[4] = {sh[i].x, sh[i].y, sh[i].z, sh[i].w};
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xv[i][k] = xa[k];
+        dn[i][k] = da[k];
+        const float z = ha[k] + xa[k] * sa[k];
+        const float sig = __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(z * -1.44269504088896340736f));
+        zz[i][k] = z;
+        sg[i][k] = sig;
+        xh[i][k] = (c < nch) ? z * sig : 0.f;  // x1 = silu(z)
+        s += xh[i][k];
+      }
+    }
+    const float mean = group_sum<LANES>(s) * invC;
+    float q = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i)
+      if (li + LANES * i < nch) {
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { xh[i][k] -= mean; q += xh[i][k] * xh[i][k]; }
+      }
+    const float rstd = ln_rstd(group_sum<LANES>(q) * invC);
+    float s1 = 0.f, s2 = 0.f;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const float ga[4] = {gg[i].x, gg[i].y, gg[i].z, gg[i].w};
+      float* pag = reinterpret_cast<float*>(&ag[i]);
+      float* pab = reinterpret_cast<float*>(&ab[i]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        xh[i][k] *= rstd;  // xhat
+        pag[k] += dn[i][k] * xh[i][k];
+        pab[k] += dn[i][k];
+        dn[i][k] *= ga[k];  // dxhat
+        s1 += dn[i][k];
+        s2 += dn[i][k] * xh[i][k];
+      }
+    }
+    const float m1 = group_sum<LANES>(s1) * invC, m2 = group_sum<LANES>(s2) * invC;
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = li + LANES * i;
+      if (c < nch) {
+        const float4 rq = *reinterpret_cast<const float4*>(dres + ro + 4 * c);
+        const float ra[4] = {rq.x, rq.y, rq.z, rq.w};
+        const float sa[4] = {sc1[i].x, sc1[i].y, sc1[i].z, sc1[i].w};
+        float* pas = reinterpret_cast<float*>(&asc[i]);
+        float* pah = reinterpret_cast<float*>(&ash[i]);
+        float o[4];
+#pragma unroll
+        for (int k = 0; k < 4; ++k) {
+          const float dx1 = rstd * (dn[i][k] - m1 - xh[i][k] * m2) + ra[k];
+          const float dz = dx1 * sg[i][k] * (1.0f + zz[i][k] * (1.0f - sg[i][k]));
+          o[k] = dz * sa[k];
+          pas[k] += dz * xv[i][k];
+          pah[k] += dz;
+        }
+        *reinterpret_cast<float4*>(dx + ro + 4 * c) = make_float4(o[0], o[1], o[2], o[3]);
+      }
+    }
+  }
+  __syncthreads();  // red zeroed by everyone before the first LDS add
+#pragma unroll
+  for (int i = 0; i < V; ++i) {
+    const int c = li + LANES * i;
+    if (c < nch) {
+      const float* pag = reinterpret_cast<const float*>(&ag[i]);
+      const float* pab = reinterpret_cast<const float*>(&ab[i]);
+      const float* pas = reinterpret_cast<const float*>(&asc[i]);
+      const float* pah = reinterpret_cast<const float*>(&ash[i]);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) {
+        atomicAdd(&red[4 * c + k], pag[k]);
+        atomicAdd(&red[C + 4 * c + k], pab[k]);
+        atomicAdd(&red[2 * C + 4 * c + k], pas[k]);
+        atomicAdd(&red[3 * C + 4 * c + k], pah[k]);
+      }
+    }
+  }
+  __syncthreads();
+  float* drow = dcond + (size_t)b * dcond_stride + cond_off;
+  for (int c = threadIdx.x; c < C; c += 256) {
+    atomicAdd(dg + c, red[c]);
+    atomicAdd(db + c, red[C + c]);
+    atomicAdd(drow + c, red[2 * C + c]);
+    atomicAdd(drow + C + c, red[3 * C + c]);
   }
 }
 
@@ -494,13 +634,14 @@ int launch_cast_pad_colsum(const float* x, int rows, int C, int ldx, bf16* out, 
   SWG_LAUNCH_CHECK();
   return 0;
 }
-int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, int rows, int N, int ld, float* db, hipStream_t s) {
+int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, bf16* a_out, int rows, int N, int ld, float* db,
+                           hipStream_t s) {
   if (rows <= 0) return 0;
   if (ld % 8 || N > ld) return SWG_E_SHAPE;
   if (!h || !da || !dh || !db) return SWG_E_NULL;
   const int cb = cdiv(ld, 128), rpb = fused_rpb(rows, cb);
-  SwgProfScope ps(KID_BWD_ROWS, 0.0, 6.0 * (double)rows * ld, s);
-  hipLaunchKernelGGL(k_gelu_bwd_colsum, dim3(cb, cdiv(rows, rpb)), dim3(256), 0, s, h, da, dh, rows, N, ld, rpb, db);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (a_out ? 8.0 : 6.0) * (double)rows * ld, s);
+  hipLaunchKernelGGL(k_gelu_bwd_colsum, dim3(cb, cdiv(rows, rpb)), dim3(256), 0, s, h, da, dh, a_out, rows, N, ld, rpb, db);
   SWG_LAUNCH_CHECK();
   return 0;
 }
@@ -537,6 +678,33 @@ int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int con
   if (C % 4) return SWG_E_SHAPE;
   hipLaunchKernelGGL(k_cond_bwd, dim3(B, cdiv(L, tpb)), dim3(256), (size_t)2 * C * sizeof(float), s, x, dxc, cond, cond_stride,
                      cond_off, C, L, tpb, dx, dcond, dcond_stride);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// fused LN1 + conditioning backward (k_ln_cond_bwd); C <= 1024, else the caller uses the two separate passes
+bool ln_cond_bwd_supported(int C) { return C % 4 == 0 && C <= 1024; }
+int launch_ln_cond_bwd(const float* x, const float* dxn, const float* dres, const float* g, const float* cond,
+                       int cond_stride, int cond_off, int B, int L, int C, float* dx, float* dg, float* db, float* dcond,
+                       int dcond_stride, hipStream_t s) {
+  if (B <= 0 || L <= 0) return 0;
+  if (!ln_cond_bwd_supported(C)) return SWG_E_UNSUPPORTED;
+  if (!x || !dxn || !dres || !g || !cond || !dx || !dg || !db || !dcond) return SWG_E_NULL;
+  const int chunks = max(1, min(cdiv(L, 32), cdiv(4096, B)));  // ~4096 workgroups, at least 32 rows each
+  const int tpb = cdiv(L, chunks);
+  const dim3 grid(cdiv(L, tpb), B);
+  const size_t lds = (size_t)4 * C * sizeof(float);
+  SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)B * L * C * 16.0, s);
+#define LCB(LN, VV)                                                                                                  \
+  hipLaunchKernelGGL((k_ln_cond_bwd<LN, VV>), grid, dim3(256), lds, s, x, dxn, dres, g, cond, cond_stride, cond_off, C, L, \
+                     tpb, dx, dg, db, dcond, dcond_stride)
+  const int nch = C / 4;
+  if (nch <= 32) LCB(32, 1);
+  else if (nch <= 64) LCB(64, 1);
+  else if (nch <= 128) LCB(64, 2);
+  else if (nch <= 192) LCB(64, 3);
+  else LCB(64, 4);
+#undef LCB
   SWG_LAUNCH_CHECK();
   return 0;
 }

@@ -245,7 +245,12 @@ int launch_colsum_bf16(const bf16* src, int M, int N, int ld, float* out, hipStr
 int launch_gelu_fwd(const bf16* h, bf16* a, size_t n, hipStream_t s);
 int launch_gelu_bwd(const bf16* h, const bf16* da, bf16* dh, size_t n, hipStream_t s);
 int launch_cast_pad_colsum(const float* x, int rows, int C, int ldx, bf16* out, int ldo, float* db, hipStream_t s);
-int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, int rows, int N, int ld, float* db, hipStream_t s);
+bool ln_cond_bwd_supported(int C);
+int launch_ln_cond_bwd(const float* x, const float* dxn, const float* dres, const float* g, const float* cond,
+                       int cond_stride, int cond_off, int B, int L, int C, float* dx, float* dg, float* db, float* dcond,
+                       int dcond_stride, hipStream_t s);
+int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, bf16* a_out, int rows, int N, int ld, float* db,
+                           hipStream_t s);
 int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
                   float* dg, float* db, hipStream_t s);
 int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int cond_stride, int cond_off, int B, int L, int C,

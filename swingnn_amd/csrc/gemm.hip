@@ -447,7 +447,8 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ P, 
         const int n = n0 + wn * 64 + nt * 16 + l15;
         if (n >= No) continue;
         float* o = dst + (size_t)m * No + n;
-        *o = accumulate ? *o + acc[mt][nt][r] : acc[mt][nt][r];
+        if (accumulate == 2) unsafeAtomicAdd(o, acc[mt][nt][r]);  // token slices add into `out` directly (no-return fp32 atomic)
+        else *o = accumulate ? *o + acc[mt][nt][r] : acc[mt][nt][r];
       }
     }
 }
@@ -513,7 +514,6 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
   const int tiles_m = cdiv(Mo, 128), tiles_n = cdiv(No, 128);
   const int tiles = tiles_m * tiles_n;
   int S = min(min(cdiv(512, tiles), max(rows / 256, 1)), 256);  // 2 workgroups per CU: one round
-  while (S > 1 && (size_t)S * Mo * No > partial_floats) --S;
   int kslice = round_up(cdiv(rows, S), TN_BT);
   S = cdiv(rows, kslice);
   SwgProfScope ps(KID_GEMM_TN, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
@@ -524,14 +524,10 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
     SWG_LAUNCH_CHECK();
     return 0;
   }
-  const size_t slice = (size_t)Mo * No;
-  if (!partial || partial_floats < slice * S) return SWG_E_WORKSPACE;
-  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, partial, tiles_n,
-                     tiles, S, kslice, slice, 0);
-  SWG_LAUNCH_CHECK();
-  const size_t n4 = slice / 4;
-  hipLaunchKernelGGL(k_splitk_reduce, dim3((unsigned)min((size_t)1024, (n4 + 255) / 256)), dim3(256), 0, s, partial, S, n4,
-                     slice, out);
+  // the S token slices add their tiles into `out` with fp32 atomics: no partial buffers, no reduction pass (the other
+  // parameter-gradient kernels accumulate with atomics too; the summation order across slices is not fixed)
+  hipLaunchKernelGGL(k_gemm_tn, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n,
+                     tiles, S, kslice, (size_t)0, 2);
   SWG_LAUNCH_CHECK();
   return 0;
 }
