@@ -58,6 +58,11 @@ typedef struct swg_block {
    * windows): per head, the Wq/Wk/Wv rows and the Wproj columns as an LDS image in swizzled MFMA fragment
    * order (swingnn_amd/engine.py wattn_image).  NULL -> the 4-kernel path is used. */
   const void* attn_img;
+  /* optional derived cache for the fused attention-tail + MLP kernel (C = 384): the projection weight as MFMA
+   * fragments (k-step major, rho-ordered out tiles, input columns in the slot order of the attention output)
+   * immediately followed by the mlp_stream image (swingnn_amd/engine.py proj_mlp_image).  NULL -> projection GEMM +
+   * MLP kernel. */
+  const void* proj_mlp_img;
 } swg_block;
 
 /* PatchMerging (:298-335) at input resolution res x res, input width C */
@@ -141,6 +146,11 @@ int swg_patch_embed_fwd(const swg_net* net, int32_t B, const float* x, const flo
 /* a1 + a2 + first half of a3 (:238-272): x <- silu(shift + x(1+scale)); x <- x + Attn(LN1(x)) with the
  * window partition / cyclic shift folded into addressing.  x_in, x_out [B, res*res, C] fp32. */
 int swg_wattn_fwd(const swg_block* blk, int32_t B, const float* x_in, const float* cond, int32_t cond_stride,
+                  float* x_out, void* ws, size_t ws_bytes, void* stream);
+/* One SwinTransformerBlock.forward (model/swin_gnn/swin_gnn.py:232-277) = swg_wattn_fwd then swg_ln_mlp_fwd; where
+ * the block carries proj_mlp_img (C = 384) the projection, the shortcut and the MLP half run as one kernel behind the
+ * attention core.  x_in == x_out allowed.  This is what the network pass (swg_precond_forward) runs per block. */
+int swg_block_fwd(const swg_block* blk, int32_t B, const float* x_in, const float* cond, int32_t cond_stride,
                   float* x_out, void* ws, size_t ws_bytes, void* stream);
 /* a4 + LN2 + residual (:275): x_out = x_in + fc2(GELU(fc1(LN2(x_in)))) */
 int swg_ln_mlp_fwd(const swg_block* blk, int32_t B, const float* x_in, float* x_out, void* ws, size_t ws_bytes,

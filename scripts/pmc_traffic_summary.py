@@ -13,7 +13,9 @@ def short(name):
     base = {"k_patch_embed_mfma": "k_patch_embed", "k_final_readout_mfma": "k_final_readout"}.get(base, base)
     # the names the library's own profiler tallies under (prof.hip): one per kernel symbol
     if base in ("k_gemm_nt", "k_mlp_stream", "k_wattn_ring") and m.group(2):
-        return base + "<" + m.group(2).strip("<>").split(",")[0].strip() + ">"
+        targs = [t.strip() for t in m.group(2).strip("<>").split(",")]
+        proj = base == "k_mlp_stream" and targs[-1] in ("true", "1")   # PROJ form: attention tail folded in
+        return base + "<" + targs[0] + (",proj" if proj else "") + ">"
     if base == "k_row" and m.group(2):
         mode = m.group(2).strip("<>").split(",")[-1].strip()
         base += "<" + {"0": "cond_ln", "1": "merge_ln", "2": "concat", "3": "ln_f32", "4": "breakup_ln"}.get(mode, mode) + ">"

@@ -29,7 +29,7 @@ class SwgBlock(C.Structure):
                 ("heads", C.c_int32), ("cond_off", C.c_int32),
                 ("ln1", SwgLn), ("ln2", SwgLn),
                 ("qkv", SwgLin), ("proj", SwgLin), ("fc1", SwgLin), ("fc2", SwgLin),
-                ("rpb", _fp), ("mlp_img", _fp), ("attn_img", _fp)]
+                ("rpb", _fp), ("mlp_img", _fp), ("attn_img", _fp), ("proj_mlp_img", _fp)]
 
 
 class SwgMerge(C.Structure):
@@ -108,6 +108,7 @@ SYMBOLS = {
     "swg_noise_embed": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _sz, _fp]),
     "swg_patch_embed_fwd": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _i32, _fp, _i32, _fp, _fp]),
     "swg_wattn_fwd": (C.c_int, [C.POINTER(SwgBlock), _i32, _fp, _fp, _i32, _fp, _fp, _sz, _fp]),
+    "swg_block_fwd": (C.c_int, [C.POINTER(SwgBlock), _i32, _fp, _fp, _i32, _fp, _fp, _sz, _fp]),
     "swg_ln_mlp_fwd": (C.c_int, [C.POINTER(SwgBlock), _i32, _fp, _fp, _fp, _sz, _fp]),
     "swg_patch_merge_fwd": (C.c_int, [C.POINTER(SwgMerge), _i32, _fp, _fp, _fp, _sz, _fp]),
     "swg_patch_expand_fwd": (C.c_int, [C.POINTER(SwgBreakup), _i32, _fp, _fp, _fp, _fp, _sz, _fp]),

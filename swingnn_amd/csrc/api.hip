@@ -102,6 +102,36 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
   return launch_gemm(o, Cp, (const bf16*)blk->proj.w, T, C, Cp, e2, s);
 }
 
+// One SwinTransformerBlock (:232-277).  Where the attention kernel leaves the projection to a second kernel (C = 384)
+// and the block carries the combined image, the projection, the shortcut and the whole MLP half run as ONE kernel
+// behind the attention core; otherwise the two halves run one after the other.  x_in == x_out is allowed.
+int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void* ws, size_t ws_bytes, hipStream_t s);
+bool fused_tail_ok(const swg_block* blk, int B) {
+  const int C = blk->C, L = blk->res * blk->res;
+  return blk->proj_mlp_img && blk->attn_img && mlp_stream_proj_supported(C) && L % 32 == 0 && (size_t)B * L >= 16384 &&
+         wattn_ring_supported(C, blk->heads, blk->win, blk->res) && !wattn_ring_fuses_proj(C) && wattn_ring_wants_xn(C);
+}
+int block_impl(const swg_block* blk, int B, const float* x_in, const float* cond, int cond_stride, float* x_out, void* ws,
+               size_t ws_bytes, hipStream_t s) {
+  int r = check_block(blk);
+  if (r) return r;
+  if (!x_in || !x_out || !cond) return SWG_E_NULL;
+  const int C = blk->C, L = blk->res * blk->res, T = B * L, Cp = kp(C);
+  if (fused_tail_ok(blk, B)) {
+    Carver cv(ws, ws_bytes);
+    bf16* xn = cv.take<bf16>((size_t)T * Cp);
+    bf16* o = cv.take<bf16>((size_t)T * Cp);
+    if (!cv.ok) return SWG_E_WORKSPACE;
+    if ((r = launch_cond_ln(x_in, T, C, L, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, nullptr, xn, Cp, s)))
+      return r;
+    if ((r = launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, nullptr, o, Cp, s))) return r;
+    return launch_mlp_stream_proj(C, T, L, x_in, o, Cp, cond, cond_stride, blk->cond_off, blk->proj.b, x_out,
+                                  (const bf16*)blk->proj_mlp_img, blk->fc1.b, blk->fc2.b, blk->ln2.g, blk->ln2.b, s);
+  }
+  if ((r = wattn_impl(blk, B, x_in, cond, cond_stride, x_out, ws, ws_bytes, s))) return r;
+  return mlp_impl(blk, B, x_out, x_out, ws, ws_bytes, s);
+}
+
 int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void* ws, size_t ws_bytes, hipStream_t s) {
   int r = check_block(blk);
   if (r) return r;
@@ -292,8 +322,7 @@ int run_trunk(const swg_net* net, int B, const TrunkBufs& tb, const float** out,
     }
     for (int j = 0; j < ly.n_blocks; ++j) {
       const swg_block* blk = &ly.blocks[j];
-      if ((r = wattn_impl(blk, B, cur, tb.cond, tb.cstride, A, tb.sw, tb.sb, s))) return r;
-      if ((r = mlp_impl(blk, B, A, A, tb.sw, tb.sb, s))) return r;
+      if ((r = block_impl(blk, B, cur, tb.cond, tb.cstride, A, tb.sw, tb.sb, s))) return r;
       cur = A;
     }
     if (ly.down) {
@@ -398,6 +427,12 @@ int swg_wattn_fwd(const swg_block* blk, int32_t B, const float* x_in, const floa
                   float* x_out, void* ws, size_t ws_bytes, void* stream) {
   if (B <= 0) return SWG_E_SHAPE;
   return wattn_impl(blk, B, x_in, cond, cond_stride, x_out, ws, ws_bytes, (hipStream_t)stream);
+}
+
+int swg_block_fwd(const swg_block* blk, int32_t B, const float* x_in, const float* cond, int32_t cond_stride,
+                  float* x_out, void* ws, size_t ws_bytes, void* stream) {
+  if (B <= 0) return SWG_E_SHAPE;
+  return block_impl(blk, B, x_in, cond, cond_stride, x_out, ws, ws_bytes, (hipStream_t)stream);
 }
 
 int swg_ln_mlp_fwd(const swg_block* blk, int32_t B, const float* x_in, float* x_out, void* ws, size_t ws_bytes,

@@ -293,5 +293,9 @@ int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, 
                      const float* g, const float* b, hipStream_t s);
 // mlp_stream.hip : the same for the wide stages (C = 384), LDS ring + skewed GELU pipeline, fragment-order image
 bool mlp_stream_supported(int C);
+bool mlp_stream_proj_supported(int C);
+int launch_mlp_stream_proj(int C, int T, int L, const float* x_in, const bf16* o, int ldo, const float* cond, int cond_stride,
+                           int cond_off, const float* proj_b, float* out, const bf16* img, const float* b1,
+                           const float* b2, const float* g, const float* b, hipStream_t s);
 int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                       const float* g, const float* b, hipStream_t s);

@@ -1,5 +1,11 @@
 // Fused MLP half of a Swin block for the WIDE stages (C = 384): model/swin_gnn/swin_gnn.py:275 with Mlp :19-25,
 //     x_out = x + fc2( GELU( fc1( LayerNorm2(x) ) ) )
+// PROJ form (C = 384, where the attention kernel cannot hold the projection accumulators): the attention half's tail
+// is folded in front, :137 / :272 / :238-240,
+//     x = silu(shift + x_in (1 + scale)) + proj_b + o Wproj^T      (o: the attention output, bf16, slot order)
+// as six more chunks of the same weight stream whose MFMAs accumulate straight into the fc2 accumulators; LayerNorm2
+// then reads those accumulators.  One kernel and one pass over the token rows replace the projection GEMM (read o,
+// read x_in, write x) and the MLP kernel's own read of x.
 // Same register-resident scheme as mlp_fused.hip (tokens on lanes, the fc1 accumulators ARE the fc2 operand), but
 // built for ONE wave per SIMD with 512 registers, where nothing but the instruction order hides latency:
 //  * hidden chunks of HC features stream through an NBUF-deep LDS ring by LDS-DMA; the ring is waited for with a
@@ -26,6 +32,12 @@ struct MlpArgs {
   const float* g;    // LN2 weight
   const float* b;    // LN2 bias
   int T;
+  // PROJ form only
+  const bf16* o;     // attention output [T, ldo], channel slots as k_wattn_ring stores them
+  int ldo;
+  const float* pb;   // proj bias [C]
+  const float* cond; // conditioning rows [B, cond_stride]; this block's (scale | shift) at cond_off
+  int cond_stride, cond_off, L;
 };
 
 typedef __attribute__((ext_vector_type(2))) __bf16 bf16x2;
@@ -42,7 +54,7 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-template <int C, int HC, int NBUF, int LB>
+template <int C, int HC, int NBUF, int LB, bool PROJ>
 __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
   constexpr int KS = C / 32;        // k-steps of fc1
   constexpr int NT = C / 16;        // output feature tiles of fc2
@@ -52,6 +64,9 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
   constexpr int W1_BYTES = HC * C * 2;
   constexpr int CHUNK_BYTES = 2 * W1_BYTES;
   constexpr int PIECES = CHUNK_BYTES / 4096;  // 1-KiB LDS-DMA pieces per wave per chunk
+  constexpr int FPC = CHUNK_BYTES / 1024;     // fragments per chunk
+  constexpr int NP = PROJ ? (C * C * 2) / CHUNK_BYTES : 0;  // projection chunks in front of the MLP stream
+  static_assert(!PROJ || (C * C * 2) % CHUNK_BYTES == 0, "the projection weight is a whole number of chunks");
   static_assert(CHUNK_BYTES % 4096 == 0 && PIECES * (NBUF - 1) < 64, "vmcnt is 6 bits");
   static_assert(NBUF == 2 || NBUF == 3, "ring depth");
   extern __shared__ __attribute__((aligned(16))) char smem[];  // NBUF x CHUNK_BYTES | b1 | 2 HC zeros
@@ -96,6 +111,64 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
   // the image rows), the channels this lane loads for k-step ks, so the epilogue is a plain store ----
   bf16x8 xa[2][KS];
   f32x4 acc[NT][2];
+  unsigned bo = 0;  // byte offset of the ring slot holding the current chunk
+  if (PROJ) {
+    // ---- attention tail: acc = shortcut + proj bias, then acc += Wproj o^T over NP chunks of the stream ----
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
+      const float* row = a.x + (size_t)tok * C + 8 * lg;
+      const float* crow = a.cond + (size_t)(tok / a.L) * a.cond_stride + a.cond_off + 8 * lg;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) {
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int c = 32 * ks + 4 * hh;
+          const f32x4 xv = *reinterpret_cast<const f32x4*>(row + c);
+          const f32x4 sc = *reinterpret_cast<const f32x4*>(crow + c);
+          const f32x4 sh = *reinterpret_cast<const f32x4*>(crow + C + c);
+          const f32x4 pb = *reinterpret_cast<const f32x4*>(a.pb + 8 * lg + c);
+          f32x4 r;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) r[e] = silu_f(sh[e] + xv[e] * (sc[e] + 1.f)) + pb[e];
+          acc[2 * ks + hh][mt] = r;
+        }
+        // register peak: loads are hoisted at most across four k-steps (one exposed latency per group, not per step)
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    bf16x8 oa[2][KS];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const bf16* orow = a.o + (size_t)min(tok0 + mt * 16 + l15, a.T - 1) * a.ldo + 8 * lg;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks) oa[mt][ks] = *reinterpret_cast<const bf16x8*>(orow + 32 * ks);
+    }
+    __syncthreads();  // sb1 visible (same role as the barrier in front of the hidden loop)
+#pragma unroll
+    for (int jp = 0; jp < NP; ++jp) {
+      wait_vmcnt<(NBUF - 2) * PIECES>();
+      __builtin_amdgcn_s_barrier();
+      asm volatile("" ::: "memory");
+      const unsigned prev = (bo == 0) ? (NBUF - 1) * CHUNK_BYTES : bo - CHUNK_BYTES;
+      const char* cb = smem + bo + lane * 16;
+      bf16x8 fr[7];
+#pragma unroll
+      for (int p = 0; p < 6; ++p) fr[p] = *reinterpret_cast<const bf16x8*>(cb + p * 1024);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int p = 0; p < FPC; ++p) {
+        const bf16x8 w = fr[p % 7];
+        const int f = jp * FPC + p, ks = f / NT, nt = f % NT;  // stream order: k-step major, rho-ordered out tile
+        acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, oa[0][ks], acc[nt][0], 0, 0, 0);
+        acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, oa[1][ks], acc[nt][1], 0, 0, 0);
+        if (p + 6 < FPC) fr[(p + 6) % 7] = *reinterpret_cast<const bf16x8*>(cb + (p + 6) * 1024);
+        if (p % (FPC / PIECES) == 1) STAGE_PIECE(jp + NBUF - 1, prev, p / (FPC / PIECES));
+        __builtin_amdgcn_sched_barrier(0);
+      }
+      bo = (bo == (NBUF - 1) * CHUNK_BYTES) ? 0u : bo + CHUNK_BYTES;
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
@@ -105,7 +178,10 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
       f32x4 p0, p1;
-      if (ROWS_FIRST) {
+      if (PROJ) {
+        p0 = acc[2 * ks][mt];
+        p1 = acc[2 * ks + 1][mt];
+      } else if (ROWS_FIRST) {
         p0 = xr[ROWS_FIRST ? mt : 0][ROWS_FIRST ? ks : 0][0];
         p1 = xr[ROWS_FIRST ? mt : 0][ROWS_FIRST ? ks : 0][1];
       } else {
@@ -120,6 +196,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
       const f32x4 c1 = *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg + 4);
       acc[2 * ks][mt] = p0 + c0;
       acc[2 * ks + 1][mt] = p1 + c1;
+      if (PROJ) __builtin_amdgcn_sched_barrier(0);  // register peak: no hoisting of the later k-steps' loads
     }
     s = rows_sum(s);
     const float mean = s * (1.0f / C);
@@ -142,6 +219,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
 #pragma unroll
       for (int j = 0; j < 8; ++j) f[j] = (bf16)((v[ks][j] - mean) * rstd * gg[j] + bb[j]);
       xa[mt][ks] = f;
+      if (PROJ) __builtin_amdgcn_sched_barrier(0);
     }
   }
 
@@ -164,8 +242,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
 #pragma unroll
     for (int s2 = 0; s2 < S2; ++s2) hb[mt][s2] = (u32x4){0u, 0u, 0u, 0u};
 
-  __syncthreads();  // sb1 visible (the LDS-DMA above is inline asm: no vmcnt(0) is emitted for it here)
-  unsigned bo = 0;  // byte offset of the ring slot holding chunk j
+  if (!PROJ) __syncthreads();  // sb1 visible (the LDS-DMA above is inline asm: no vmcnt(0) is emitted for it here)
 #pragma nounroll
   for (int j = 0; j < NCH + 2; ++j) {
     // chunk j has landed in every wave's view; NBUF-2 younger chunks may stay in flight
@@ -176,7 +253,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
     asm volatile("" ::: "memory");  // no LDS read of this iteration may move above the barrier
     // every wave is now past its reads of the slot used one iteration ago: it is refilled piece by piece below
     const unsigned prev = (bo == 0) ? (NBUF - 1) * CHUNK_BYTES : bo - CHUNK_BYTES;
-    const int next_chunk = min(j + NBUF - 1, NCH + 1);
+    const int next_chunk = NP + min(j + NBUF - 1, NCH + 1);
     const char* cb = smem + bo + lane * 16;
     const float* bj = sb1 + j * HC + 4 * lg;
 
@@ -262,12 +339,12 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
   }
 }
 
-template <int C, int HC, int NBUF, int LB>
+template <int C, int HC, int NBUF, int LB, bool PROJ>
 int launch_one(const MlpArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)NBUF * (4 * HC * C) + (size_t)(4 * C + 2 * HC) * sizeof(float);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
-  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_stream<C, HC, NBUF, LB>, (int)((int)lds))) return e;
-  hipLaunchKernelGGL((k_mlp_stream<C, HC, NBUF, LB>), dim3(cdiv(a.T, 128)), dim3(256), lds, s, a);
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_stream<C, HC, NBUF, LB, PROJ>, (int)((int)lds))) return e;
+  hipLaunchKernelGGL((k_mlp_stream<C, HC, NBUF, LB, PROJ>), dim3(cdiv(a.T, 128)), dim3(256), lds, s, a);
   return 0;
 }
 
@@ -279,9 +356,28 @@ int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img,
                       const float* g, const float* b, hipStream_t s) {
   if (!mlp_stream_supported(C)) return SWG_E_UNSUPPORTED;
   if (T <= 0) return 0;
-  MlpArgs a = {x, out, img, b1, b2, g, b, T};
+  MlpArgs a = {x, out, img, b1, b2, g, b, T, nullptr, 0, nullptr, nullptr, 0, 0, 1};
   SwgProfScope ps(C == 384 ? KID_MLP_STREAM_384 : KID_MLP_STREAM, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
-  int rc = (C == 384) ? launch_one<384, 32, 3, 1>(a, s) : launch_one<192, 64, 3, 1>(a, s);
+  int rc = (C == 384) ? launch_one<384, 32, 3, 1, false>(a, s) : launch_one<192, 64, 3, 1, false>(a, s);
+  if (rc) return rc;
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// attention tail + MLP half in one kernel (PROJ form above).  x_in: the BLOCK input (the shortcut is recomputed from
+// it), o: attention output [T, ldo] bf16, img: projection fragments followed by the mlp_stream image.  x_in == out is
+// allowed (a wave reads only the rows it writes).
+bool mlp_stream_proj_supported(int C) { return C == 384; }
+int launch_mlp_stream_proj(int C, int T, int L, const float* x_in, const bf16* o, int ldo, const float* cond, int cond_stride,
+                           int cond_off, const float* proj_b, float* out, const bf16* img, const float* b1,
+                           const float* b2, const float* g, const float* b, hipStream_t s) {
+  if (!mlp_stream_proj_supported(C)) return SWG_E_UNSUPPORTED;
+  if (T <= 0) return 0;
+  if (L <= 0 || L % 32 || T % L || ldo < C || ldo % 8) return SWG_E_SHAPE;  // a wave's 32 tokens lie in one graph
+  if (!x_in || !o || !cond || !proj_b || !out || !img) return SWG_E_NULL;
+  MlpArgs a = {x_in, out, img, b1, b2, g, b, T, o, ldo, proj_b, cond, cond_stride, cond_off, L};
+  SwgProfScope ps(KID_MLP_PROJ_384, 18.0 * T * (double)C * C, 10.0 * T * (double)C + 18.0 * C * C, s);
+  int rc = launch_one<384, 32, 3, 1, true>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();
   return 0;

@@ -35,6 +35,7 @@ enum SwgKernelId {
   KID_GEMM_TN,
   KID_MLP_STREAM_384,
   KID_WATTN_RING_384,
+  KID_MLP_PROJ_384,
   KID_COUNT
 };
 

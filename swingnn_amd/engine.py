@@ -87,6 +87,25 @@ class Keep:
             self.registry.append(("gather", tuple(srcs), img, idx))
         return img
 
+    def image_pair(self, fn_a, srcs_a, args_a, fn_b, srcs_b, args_b):
+        """Two images in ONE allocation, b directly behind a (a kernel streams across the seam); each half is
+        registered for the in-place refresh on its own.  -> (whole, view of a, view of b)"""
+        a, b = fn_a(*srcs_a, *args_a), fn_b(*srcs_b, *args_b)
+        whole = self(torch.cat([a.reshape(-1), b.reshape(-1)]))
+        va, vb = whole[:a.numel()], whole[a.numel():]
+        if self.registry is not None:
+            for fn, srcs, args, view in ((fn_a, srcs_a, args_a, va), (fn_b, srcs_b, args_b, vb)):
+                off, fake = 1, []
+                for w in srcs:
+                    n = w.numel()
+                    assert off + n < (1 << 24)
+                    fake.append(torch.arange(off, off + n, dtype=torch.float32, device=w.device).view(w.shape))
+                    off += n
+                idx = self(fn(*fake, *args, dtype=torch.float32).round().to(torch.int32).reshape(-1).contiguous())
+                assert idx.numel() == view.numel()
+                self.registry.append(("gather", tuple(srcs), view, idx))
+        return whole, va, vb
+
     def f32(self, t):
         return _ptr(self(_f32(t)))
 
@@ -211,6 +230,19 @@ def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int, dtype=torch.bf
     return img.to(dtype).contiguous()
 
 
+def proj_frag_image(proj_w: torch.Tensor, heads: int, dtype=torch.bfloat16) -> torch.Tensor:
+    """The attention projection weight [C, C] as MFMA fragments for the PROJ form of csrc/mlp_stream.hip: fragment
+    (k-step ks, out tile nt), k-step major, holds rows rho(nt*16 + i) and input columns ks*32 + lg*8 + e in the slot
+    order in which k_wattn_ring stores o (slot h*32 + 8lg + e = head dim pi(lg, e))."""
+    proj_w = proj_w.detach().float()
+    Cdim = proj_w.shape[0]
+    dev = proj_w.device
+    wp = proj_w.reshape(Cdim, heads, 32)[..., _pi(dev)].reshape(Cdim, Cdim)        # columns in o's slot order
+    w = wp[_rho(Cdim, dev)].reshape(Cdim // 16, 16, Cdim // 32, 4, 8)               # [nt, i, ks, lg, e]
+    return w.permute(2, 0, 3, 1, 4).reshape(-1).to(dtype).contiguous()             # [ks, nt, lg, i, e]
+
+
+PROJ_MLP_DIMS = (384,)   # channel counts with the fused attention-tail + MLP kernel (csrc/mlp_stream.hip, PROJ form)
 USE_FUSED_ATTN = True
 
 
@@ -268,15 +300,24 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
             and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % blk.window_size == 0):
         aimg = _ptr(keep.image(wattn_ring_image, (blk.attn.qkv.weight, blk.attn.proj.weight), blk.num_heads,
                                RING_ATTN_FUSED_PROJ[blk.dim]))
+    pimg = None
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
         img = _ptr(keep.image(mlp_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
+    elif (USE_FUSED_MLP and blk.dim in PROJ_MLP_DIMS and aimg is not None and not RING_ATTN_FUSED_PROJ[blk.dim]
+          and blk.dim in STREAM_MLP_HC):
+        # projection fragments + MLP stream in one allocation: the fused kernel streams across the seam, the plain
+        # MLP kernel starts at the second half
+        whole, _, vb = keep.image_pair(proj_frag_image, (blk.attn.proj.weight,), (blk.num_heads,),
+                                       mlp_stream_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight),
+                                       (STREAM_MLP_HC[blk.dim],))
+        pimg, img = _ptr(whole), _ptr(vb)
     elif USE_FUSED_MLP and blk.dim in STREAM_MLP_HC:
         img = _ptr(keep.image(mlp_stream_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight), STREAM_MLP_HC[blk.dim]))
     return L.SwgBlock(blk.dim, blk.input_resolution[0], blk.window_size, blk.shift_size, blk.num_heads, cond_off,
                       keep.ln(blk.norm1), keep.ln(blk.norm2),
                       keep.lin(blk.attn.qkv.weight, blk.attn.qkv.bias), keep.lin(blk.attn.proj.weight, blk.attn.proj.bias),
                       keep.lin(blk.mlp.fc1.weight, blk.mlp.fc1.bias), keep.lin(blk.mlp.fc2.weight, blk.mlp.fc2.bias),
-                      keep.f32(blk.attn.relative_position_bias_table), img, aimg)
+                      keep.f32(blk.attn.relative_position_bias_table), img, aimg, pimg)
 
 
 def merge_desc(keep: Keep, m) -> L.SwgMerge:

@@ -67,7 +67,7 @@ class WindowAttention(nn.Module):
 
 
 class SwinTransformerBlock(nn.Module):
-    """Reference :158-277.  forward(x [B,L,C], emb [B,512]) -> [B,L,C] through swg_wattn_fwd + swg_ln_mlp_fwd."""
+    """Reference :158-277.  forward(x [B,L,C], emb [B,512]) -> [B,L,C] through swg_block_fwd (= swg_wattn_fwd + swg_ln_mlp_fwd)."""
 
     def __init__(self, dim, noise_emb_channels, input_resolution, num_heads, window_size=7, shift_size=0,
                  mlp_ratio=4., qkv_bias=True, qk_scale=None, drop=0., attn_drop=0., drop_path=0.,
@@ -110,10 +110,8 @@ class SwinTransformerBlock(nn.Module):
         cond = torch.addmm(self.affine.bias, E._as_f32(emb), self.affine.weight.t()).contiguous()  # tiny [B,2C] GEMV
         out = torch.empty_like(x)
         ws = E.workspace(x.device, 64 * x.numel() + (1 << 20))
-        _run(L.lib.swg_wattn_fwd, "swg_wattn_fwd", C.byref(desc), B, x.data_ptr(), cond.data_ptr(), 2 * Cdim,
+        _run(L.lib.swg_block_fwd, "swg_block_fwd", C.byref(desc), B, x.data_ptr(), cond.data_ptr(), 2 * Cdim,
              out.data_ptr(), ws.data_ptr(), ws.numel(), E.stream_ptr())
-        _run(L.lib.swg_ln_mlp_fwd, "swg_ln_mlp_fwd", C.byref(desc), B, out.data_ptr(), out.data_ptr(),
-             ws.data_ptr(), ws.numel(), E.stream_ptr())
         return out
 
 

@@ -76,6 +76,39 @@ def test_precond_full_size(name, monkeypatch):
         pre.assert_symmetric()
 
 
+def test_precond_grid384_batched_pass_matches_oracle(monkeypatch):
+    """The bench geometry at a batch large enough for the batch-dependent kernel choices of the C = 384 stage (32 graphs
+    x 576 tokens >= 16384: streamed MLP, fused attention-tail + MLP kernel, the next block's LayerNorm1 produced by the
+    previous block's tail), which the B = 1 cases above do not reach.  Every graph is held to the oracle."""
+    import swingnn_amd as S
+    c = FULL_CASES["grid384"]
+    cfg = dict(img_size=c["img"], patch_size=c["p"], in_chans=1, embed_dim=c["dim"], depths=c["depths"],
+               num_heads=HEADS, window_size=c["window"], self_condition=True)
+    net = S.SwinGNN(img_size=c["img"], patch_size=c["p"], in_chans=1, embed_dim=c["dim"], depths=c["depths"],
+                    num_heads=HEADS, window_size=c["window"], mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                    drop_path_rate=0.0, self_condition=True)
+    pre = S.Precond("edm", net, True)
+    sd = filler.fill_state_dict(pre.state_dict(), c["seed"], "init")
+    pre.load_state_dict(sd)
+    pre = pre.to(DEV).eval()
+    N, B = c["img"], 32
+    n_nodes = torch.tensor([361 - 7 * (i % 5) for i in range(B)])
+    flags = (torch.arange(N)[None, :] < n_nodes[:, None]).to(torch.float32)
+    sig = torch.tensor([0.05 + 0.4 * i for i in range(B)], dtype=torch.float32)
+    x = torch.cat([filler.sym_adj("x", 1, N, flags[i:i + 1], c["seed"] + 100 + i,
+                                  scale=float(np.sqrt(float(sig[i]) ** 2 + 0.25))) for i in range(B)])
+    monkeypatch.setattr(np.random, "rand", lambda: 0.25)   # self-conditioning branch: two passes
+    out = pre(x.to(DEV), flags.to(DEV), sig.to(DEV)).cpu()
+    monkeypatch.undo()
+    pre.assert_symmetric()
+    ref = O.precond_forward(sd, cfg, x, flags, sig, True)
+    err = float((out - ref).abs().max())
+    raw, filt = agreement(out, ref, flags)
+    print(f"grid384 B={B}: max err {err:.3g}, agreement raw {raw:.5f} filtered {filt:.5f}")
+    assert err <= 1e-2, err
+    assert filt >= 0.999 and raw >= 0.999, (raw, filt)
+
+
 # C=768 with UN-clamped windows (the last stage of the full-size nets: res 12 / w 6 and res 16 / w 8, 4 windows per
 # graph), which no reduced golden geometry reaches; shifted variants exercise the mask path of that kernel route.
 BIG_BLOCK_CASES = {
@@ -106,6 +139,46 @@ def test_block_full_size(name):
             rel_close(out, ref)
         else:
             rel_close(out, ref, 5e-3, 5e-4)
+
+
+@pytest.mark.parametrize("shift,in_place", [(0, False), (3, True)])
+def test_block_fused_tail_matches_two_kernel_path(shift, in_place):
+    """C = 384 at the bench's token count per launch (56 graphs x 24 x 24 tokens): swg_block_fwd runs the projection,
+    the shortcut and the MLP half as ONE kernel behind the attention core (mlp_stream.hip, PROJ form).  It must agree
+    with swg_wattn_fwd + swg_ln_mlp_fwd (projection GEMM, separate MLP kernel: same bf16 operands, fp32 accumulation in
+    another order), and -- on a few graphs -- with the oracle to the block bar."""
+    import ctypes as C
+    import swingnn_amd as S
+    from swingnn_amd import _lib as L, engine as E
+    Cd, res, heads, win, B = 384, 24, 12, 6, 56
+    full = H.block_state(Cd, heads, win, 91, regime="stress")
+    blk = load(S.SwinTransformerBlock(Cd, 512, (res, res), heads, win, shift), strip(full, "blk."))
+    x = filler.uniform("x", (B, res * res, Cd), 91)
+    emb = filler.uniform("emb", (B, 512), 91)
+    xd = x.to(DEV)
+    cond = torch.addmm(blk.affine.bias, emb.to(DEV), blk.affine.weight.t()).contiguous()
+    keep = E.Keep()
+    d = E.block_desc(keep, blk, 0)
+    assert d.proj_mlp_img, "the block must carry the combined projection + MLP image"
+    ws = torch.empty(1 << 30, dtype=torch.uint8, device=DEV)
+    two = torch.empty_like(xd)
+    L.check(L.lib.swg_wattn_fwd(C.byref(d), B, xd.data_ptr(), cond.data_ptr(), 2 * Cd, two.data_ptr(), ws.data_ptr(),
+                                ws.numel(), E.stream_ptr()), "wattn")
+    L.check(L.lib.swg_ln_mlp_fwd(C.byref(d), B, two.data_ptr(), two.data_ptr(), ws.data_ptr(), ws.numel(),
+                                 E.stream_ptr()), "mlp")
+    buf = xd.clone() if in_place else torch.empty_like(xd)
+    src = buf if in_place else xd
+    L.check(L.lib.swg_block_fwd(C.byref(d), B, src.data_ptr(), cond.data_ptr(), 2 * Cd, buf.data_ptr(), ws.data_ptr(),
+                                ws.numel(), E.stream_ptr()), "block")
+    torch.cuda.synchronize()
+    # the fp32 attention-half result differs in its last bits (summation order), which flips some bf16 roundings of the
+    # LN2 output: isolated entries move by a bf16 ulp of an operand, the bulk agrees to fp32 rounding
+    scale = float(two.abs().max())
+    diff = (buf - two).abs()
+    assert float(diff.max()) <= 3e-3 * scale, float(diff.max()) / scale
+    assert float(diff.mean()) <= 5e-5 * scale, float(diff.mean()) / scale
+    ref = O.swin_block(x[:2], emb[:2], full, "blk", res, heads, win, shift)
+    rel_close(buf[:2].cpu(), ref)
 
 
 @pytest.fixture(scope="module")
