@@ -4,11 +4,14 @@ sys.path.insert(0, __import__('os').path.dirname(__import__('os').path.dirname(_
 import bench
 from swingnn_amd import engine as E
 torch.set_grad_enabled(False)
-cfg = bench.CONFIGS['grid']
+cfgname = sys.argv[1] if len(sys.argv) > 1 else 'grid'
+cfg = bench.CONFIGS[cfgname]
 dev = torch.device('cuda:0')
 model = bench.build_model(cfg, dev)
 np.random.rand = lambda: 0.9
-for B, parts in [(112, 1), (112, 2), (168, 2), (168, 3), (224, 2), (224, 4), (280, 5), (84, 3), (56, 2), (56, 1)]:
+combos = {'grid': [(112, 1), (112, 2), (168, 2), (168, 3), (224, 2), (224, 4), (280, 5), (84, 3), (56, 2), (56, 1)],
+          'dd': [(56, 1), (56, 2), (112, 2), (112, 1), (112, 4), (84, 3), (28, 1)]}[cfgname]
+for B, parts in combos:
     E.SPLIT_STREAMS = parts
     E.SPLIT_MIN_WORK = 0
     flags = bench.make_flags(cfg, B, np.random.default_rng(0)).to(dev)
