@@ -574,8 +574,11 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   const int nwg = cdiv(B * nW, 4);
   const double T = (double)B * blk->res * blk->res;
   const double gemm = wattn_ring_fuses_proj(C) ? 8.0 : 6.0;
+  // algorithmic bytes per token and channel: fused projection: x in (4, shortcut) + out (4) [+ 2 for the pre-normalised
+  // bf16 rows]; attention core only: normalised rows in (2) + o out (2).  Weights: one pass of the stream (2 B each).
+  const double row_bytes = wattn_ring_fuses_proj(C) ? (xn ? 10.0 : 8.0) : 4.0;
   SwgProfScope ps(C == 384 ? KID_WATTN_RING_384 : KID_WATTN_RING, gemm * T * C * C + 4.0 * T * (blk->win * blk->win) * C,
-                  (gemm == 8.0 ? 8.0 : 6.0) * T * C + gemm * C * C, s);
+                  row_bytes * T * C + gemm * C * C, s);
   int r;
   if (blk->win == 8) {
     if (C == 192) r = launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s);
