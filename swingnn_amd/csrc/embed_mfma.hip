@@ -34,7 +34,7 @@ __device__ __forceinline__ void split_bf16(const float (&f)[8], bf16x8& hi, bf16
 __device__ __forceinline__ int rho_chan(int nt, int i) { return 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3); }
 
 template <int C>
-__global__ __launch_bounds__(256) void k_patch_embed_mfma(EmbedMfmaArgs a) {
+__global__ __launch_bounds__(256, 4) void k_patch_embed_mfma(EmbedMfmaArgs a) {
   constexpr int NT = C / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -52,9 +52,8 @@ __global__ __launch_bounds__(256) void k_patch_embed_mfma(EmbedMfmaArgs a) {
     }
     split_bf16(f, wh[nt], wl[nt]);
   }
-  f32x4 cb[NT];  // conv bias of this lane's channels (LN weight / bias are re-read per tile: L1 hits, 48 VGPRs less)
-#pragma unroll
-  for (int nt = 0; nt < NT; ++nt) cb[nt] = *reinterpret_cast<const f32x4*>(a.bias + rho_chan(nt, 4 * lg));
+  // conv bias, LN weight / bias of this lane's channels are re-read per tile (L1 hits): 72 VGPRs less, which is the
+  // difference between two and four waves per SIMD for this HBM-bound kernel
 
   const int hp = a.N >> 2, L = hp * hp, rows = a.B * L;
   const int ntiles = (rows + 15) >> 4;
@@ -93,7 +92,8 @@ __global__ __launch_bounds__(256) void k_patch_embed_mfma(EmbedMfmaArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xh, cb[nt], 0, 0, 0);
+      const f32x4 cb = *reinterpret_cast<const f32x4*>(a.bias + rho_chan(nt, 4 * lg));
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xh, cb, 0, 0, 0);
       acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xl, acc[nt], 0, 0, 0);
       acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], xh, acc[nt], 0, 0, 0);
     }
@@ -134,7 +134,7 @@ struct ReadoutMfmaArgs {
 };
 
 template <int C>
-__global__ __launch_bounds__(256) void k_final_readout_mfma(ReadoutMfmaArgs a) {
+__global__ __launch_bounds__(256, 4) void k_final_readout_mfma(ReadoutMfmaArgs a) {
   constexpr int KS = C / 32;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -213,7 +213,7 @@ struct BreakupPostArgs {
 };
 
 template <int CO>
-__global__ __launch_bounds__(256) void k_breakup_post(BreakupPostArgs a) {
+__global__ __launch_bounds__(256, 2) void k_breakup_post(BreakupPostArgs a) {
   constexpr int KS = CO / 32, NT = CO / 16, CIN = 4 * CO;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
