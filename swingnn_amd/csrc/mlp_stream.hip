@@ -358,7 +358,7 @@ int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img,
   if (T <= 0) return 0;
   MlpArgs a = {x, out, img, b1, b2, g, b, T, nullptr, 0, nullptr, nullptr, 0, 0, 1};
   SwgProfScope ps(C == 384 ? KID_MLP_STREAM_384 : KID_MLP_STREAM, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
-  int rc = (C == 384) ? launch_one<384, 32, 3, 1, false>(a, s) : launch_one<192, 64, 3, 1, false>(a, s);
+  int rc = (C == 384) ? launch_one<384, 32, 3, 1, false>(a, s) : launch_one<192, 32, 3, 1, false>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();
   return 0;

@@ -207,7 +207,7 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch
     return torch.cat([a, b], dim=1).to(dtype).contiguous()
 
 
-STREAM_MLP_HC = {384: 32, 192: 64}  # hidden chunk width of csrc/mlp_stream.hip per channel count
+STREAM_MLP_HC = {384: 32, 192: 32}  # hidden chunk width of csrc/mlp_stream.hip per channel count
 
 
 def mlp_stream_image(w1: torch.Tensor, w2: torch.Tensor, hc: int, dtype=torch.bfloat16) -> torch.Tensor:
