@@ -158,7 +158,6 @@ int mlp_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const f
 int merge_bwd_impl(const swg_merge* m, const swg_merge_train* tr, int B, const float* x_in, const float* dy, float* dx,
                    Carver& cv, hipStream_t s) {
   const int C = m->C, K4 = 4 * C, N2 = 2 * C, T4 = B * (m->res / 2) * (m->res / 2), K4p = kp(K4), N2p = kp(N2);
-  float* xg = cv.take<float>((size_t)T4 * K4);
   bf16* xn = cv.take<bf16>((size_t)T4 * K4p);
   bf16* dyb = cv.take<bf16>((size_t)T4 * N2p);
   float* dxn = cv.take<float>((size_t)T4 * K4);
@@ -168,15 +167,15 @@ int merge_bwd_impl(const swg_merge* m, const swg_merge_train* tr, int B, const f
   int r;
   if ((r = check_lin_train(tr->red, false))) return r;
   if (!tr->ln.dg || !tr->ln.db) return SWG_E_NULL;
-  if ((r = launch_perm22(x_in, xg, B, m->res, C, 0, s))) return r;
-  if ((r = launch_cond_ln(xg, T4, K4, 1, nullptr, 0, 0, m->ln.g, m->ln.b, nullptr, xn, K4p, s))) return r;
+  // recompute: 2x2 gather + LayerNorm(4C) in one pass (the forward kernel); the gathered fp32 rows are never stored
+  if ((r = launch_merge_ln(x_in, B, m->res, C, m->ln.g, m->ln.b, xn, K4p, s))) return r;
   if ((r = launch_cast_pad(dy, T4, N2, N2, dyb, N2p, s))) return r;
   GemmEpi e = {};
   e.out_f32 = dxn; e.ldo = K4;
   if ((r = launch_gemm(dyb, N2p, (const bf16*)tr->red.wt, T4, K4, N2p, e, s))) return r;
   if ((r = wgrad_tn(dyb, N2p, N2, xn, K4p, K4, T4, tr->red.dw, w, s))) return r;
-  if ((r = launch_ln_bwd(xg, dxn, m->ln.g, nullptr, T4, K4, dxn, tr->ln.dg, tr->ln.db, s))) return r;
-  return launch_perm22(dxn, dx, B, m->res, C, 1, s);
+  // LayerNorm backward with the gather (x) and the scatter (dx) folded into its addressing
+  return launch_ln_bwd(x_in, dxn, m->ln.g, nullptr, T4, K4, dx, tr->ln.dg, tr->ln.db, s, m->res, 1 | 4);
 }
 
 int expand_bwd_impl(const swg_breakup* u, const swg_breakup_train* tr, int B, const float* x, const float* skip,
@@ -184,7 +183,6 @@ int expand_bwd_impl(const swg_breakup* u, const swg_breakup_train* tr, int B, co
   const int Cin = u->Cin, Co = Cin / 4, T = B * u->res * u->res, T4 = 4 * T, Kp = kp(Cin), Cop = kp(Co);
   bf16* cat = cv.take<bf16>((size_t)T * Kp);
   float* y = cv.take<float>((size_t)T * Cin);
-  float* yn = cv.take<float>((size_t)T * Cin);
   float* z = cv.take<float>((size_t)T4 * Co);
   bf16* zn = cv.take<bf16>((size_t)T4 * Cop);
   bf16* dyb = cv.take<bf16>((size_t)T4 * Cop);
@@ -202,9 +200,8 @@ int expand_bwd_impl(const swg_breakup* u, const swg_breakup_train* tr, int B, co
   GemmEpi e = {};
   e.out_f32 = y; e.ldo = Cin;
   if ((r = launch_gemm(cat, Kp, (const bf16*)u->pre.w, T, Cin, Kp, e, s))) return r;
-  if ((r = launch_ln_f32(y, T, Cin, u->ln.g, u->ln.b, yn, s))) return r;
-  if ((r = launch_perm22(yn, z, B, 2 * u->res, Co, 1, s))) return r;
-  if ((r = launch_cond_ln(z, T4, Co, 1, nullptr, 0, 0, u->post_ln.g, u->post_ln.b, nullptr, zn, Cop, s))) return r;
+  // norm (Cin) + 2x2 scatter + post_norm (Co) in one pass over y (the forward kernel), which also leaves z
+  if ((r = launch_breakup_ln2(y, B, u->res, Cin, u->ln.g, u->ln.b, u->post_ln.g, u->post_ln.b, zn, Cop, s, z))) return r;
   // ---- post_linear, post_norm ----
   if ((r = launch_cast_pad(dy, T4, Co, Co, dyb, Cop, s))) return r;
   GemmEpi e1 = {};
@@ -213,8 +210,8 @@ int expand_bwd_impl(const swg_breakup* u, const swg_breakup_train* tr, int B, co
   if ((r = wgrad_tn(dyb, Cop, Co, zn, Cop, Co, T4, tr->post.dw, w, s))) return r;
   if ((r = launch_ln_bwd(z, dzn, u->post_ln.g, nullptr, T4, Co, dzn, tr->post_ln.dg, tr->post_ln.db, s))) return r;
   // ---- scatter, norm, pre_linear ----
-  if ((r = launch_perm22(dzn, dyn, B, 2 * u->res, Co, 0, s))) return r;
-  if ((r = launch_ln_bwd(y, dyn, u->ln.g, nullptr, T, Cin, dyn, tr->ln.dg, tr->ln.db, s))) return r;
+  // norm backward reads its upstream gradient through the 2x2 gather (dzn is in token layout)
+  if ((r = launch_ln_bwd(y, dzn, u->ln.g, nullptr, T, Cin, dyn, tr->ln.dg, tr->ln.db, s, 2 * u->res, 2))) return r;
   if ((r = launch_cast_pad(dyn, T, Cin, Cin, dyb2, Kp, s))) return r;
   const bf16* wt = (const bf16*)tr->pre.wt;  // [Cin (input feature), Kp]: rows [0, Cin/2) belong to x, the rest to skip
   GemmEpi e2 = {};

@@ -169,11 +169,15 @@ __global__ __launch_bounds__(256) void k_gelu_bwd_colsum(const bf16* __restrict_
 // ---- LayerNorm backward: one wavefront per row (grid-stride), V float4 chunks per lane ----
 //   xhat = (x - mean) rstd, dxhat = dy g, dx = rstd (dxhat - mean(dxhat) - xhat mean(dxhat xhat)) [+ dres]
 //   dg += sum_rows dy xhat, db += sum_rows dy
+// Optional 2x2 patch permutation folded into the addressing (PatchMerging / PatchBreakup, k_perm22 below): with
+// perm_res > 0 a row is the PACKED row (b, Y, X) of 4 tokens x Cs channels and the operands named in perm_mask
+// (1: x, 2: dy, 4: dx) live in TOKEN layout [B, perm_res^2, Cs]; chunk c of the row is channel chunk c % (Cs/4) of token
+// (2Y + (k&1), 2X + (k>>1)), k = c / (Cs/4).
 template <int V>
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                 const float* __restrict__ g, const float* __restrict__ dres, int rows,
                                                 int C, float* __restrict__ dx, float* __restrict__ dg,
-                                                float* __restrict__ db) {
+                                                float* __restrict__ db, int perm_res, int perm_mask) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 2;
@@ -185,16 +189,32 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
     gg[i] = (c < nch) ? *reinterpret_cast<const float4*>(g + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
   const float invC = 1.0f / (float)C;
+  const int pcs = nch >> 2, r2 = perm_res >> 1;  // chunks per token; packed grid side
   for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
     float4 xv[V], dv[V];
     float s = 0.f;
+    size_t ptok = 0;  // token (2Y, 2X) of the packed row
+    if (perm_res) {
+      const int X = row % r2, t = row / r2, Y = t % r2, b = t / r2;
+      ptok = ((size_t)b * perm_res + 2 * Y) * perm_res + 2 * X;
+    }
+    size_t po[V];  // element offset of chunk i in token layout
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int c = lane + 64 * i;
+      po[i] = 0;
+      if (perm_res && c < nch) {
+        const int k = c / pcs, cc = c - k * pcs;
+        po[i] = (ptok + (size_t)(k & 1) * perm_res + (k >> 1)) * (size_t)(4 * pcs) + 4 * cc;
+      }
+    }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
       const int c = lane + 64 * i;
       xv[i] = dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
       if (c < nch) {
-        xv[i] = *reinterpret_cast<const float4*>(x + (size_t)row * C + 4 * c);
-        dv[i] = *reinterpret_cast<const float4*>(dy + (size_t)row * C + 4 * c);
+        xv[i] = *reinterpret_cast<const float4*>(x + ((perm_mask & 1) ? po[i] : (size_t)row * C + 4 * c));
+        dv[i] = *reinterpret_cast<const float4*>(dy + ((perm_mask & 2) ? po[i] : (size_t)row * C + 4 * c));
       }
       s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
     }
@@ -229,7 +249,7 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
           const float4 r = *reinterpret_cast<const float4*>(dres + (size_t)row * C + 4 * c);
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        *reinterpret_cast<float4*>(dx + (size_t)row * C + 4 * c) = o;
+        *reinterpret_cast<float4*>(dx + ((perm_mask & 4) ? po[i] : (size_t)row * C + 4 * c)) = o;
       }
     }
   }
@@ -647,15 +667,18 @@ int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, bf16* a_out,
 }
 
 int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
-                  float* dg, float* db, hipStream_t s) {
+                  float* dg, float* db, hipStream_t s, int perm_res, int perm_mask) {
   if (rows <= 0) return 0;
   if (C % 4 || C > 3072) return SWG_E_UNSUPPORTED;
+  if (perm_res && (C % 16 || perm_res % 2 || dres)) return SWG_E_SHAPE;
+  if (!perm_res) perm_mask = 0;
   if (!x || !dy || !g || !dx || !dg || !db) return SWG_E_NULL;
   const int V = cdiv(C / 4, 64);
   const int grid = min(cdiv(rows, 4), 1024);
   const size_t lds = (size_t)2 * C * sizeof(float);
   SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)rows * C * (dres ? 16.0 : 12.0), s);
-#define LNB(VV) hipLaunchKernelGGL((k_ln_bwd<VV>), dim3(grid), dim3(256), lds, s, x, dy, g, dres, rows, C, dx, dg, db)
+#define LNB(VV) \
+  hipLaunchKernelGGL((k_ln_bwd<VV>), dim3(grid), dim3(256), lds, s, x, dy, g, dres, rows, C, dx, dg, db, perm_res, perm_mask)
   if (V <= 1) LNB(1);
   else if (V == 2) LNB(2);
   else if (V == 3) LNB(3);

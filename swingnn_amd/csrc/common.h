@@ -183,7 +183,7 @@ int launch_ln_f32(const float* x, int rows, int C, const float* g, const float* 
 int launch_breakup_ln(const float* y, int B, int res, int Co, const float* g, const float* b, bf16* out, int ldo,
                       hipStream_t s);
 int launch_breakup_ln2(const float* y, int B, int res, int Cin, const float* g1, const float* b1, const float* g2,
-                       const float* b2, bf16* out, int ldo, hipStream_t s);
+                       const float* b2, bf16* out, int ldo, hipStream_t s, float* z_out = nullptr);
 int launch_gemv_rows(const float* W, const float* bias, const float* x, int Bx, int N, int K, int act, float* out,
                      hipStream_t s);
 int launch_pos_embed(const float* labels, int Bc, const float* freqs, int nf, float* out, hipStream_t s);
@@ -252,7 +252,7 @@ int launch_ln_cond_bwd(const float* x, const float* dxn, const float* dres, cons
 int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, bf16* a_out, int rows, int N, int ld, float* db,
                            hipStream_t s);
 int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
-                  float* dg, float* db, hipStream_t s);
+                  float* dg, float* db, hipStream_t s, int perm_res = 0, int perm_mask = 0);
 int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int cond_stride, int cond_off, int B, int L, int C,
                     float* dx, float* dcond, int dcond_stride, hipStream_t s);
 int launch_perm22(const float* src, float* dst, int B, int res, int C, int dir, hipStream_t s);

@@ -207,6 +207,7 @@ struct Breakup2Args {
   const float* y; const float* g1; const float* b1; const float* g2; const float* b2;
   bf16* out;
   int rows, res, Cin, Co, ldo;
+  float* z;  // optional: the scattered rows BEFORE the second LayerNorm, fp32 [4 rows, Co] (the backward pass needs them)
 };
 
 template <int LANES, int V>
@@ -265,6 +266,13 @@ __global__ __launch_bounds__(256) void k_breakup_ln2(Breakup2Args a) {
   const int dy = k & 1, dx = k >> 1;
   const size_t drow = (size_t)bi * 4 * a.res * a.res + (size_t)(2 * yy + dy) * 2 * a.res + (2 * xx + dx);
   const int nst = a.ldo >> 2;
+  if (a.z) {
+#pragma unroll
+    for (int i = 0; i < V; ++i) {
+      const int j = jq + i * Q;
+      if (j < cq) *reinterpret_cast<float4*>(a.z + drow * a.Co + 4 * j) = v[i];
+    }
+  }
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     const int j = jq + i * Q;
@@ -282,9 +290,9 @@ __global__ __launch_bounds__(256) void k_breakup_ln2(Breakup2Args a) {
 }
 
 int launch_breakup_ln2(const float* y, int B, int res, int Cin, const float* g1, const float* b1, const float* g2,
-                       const float* b2, bf16* out, int ldo, hipStream_t s) {
+                       const float* b2, bf16* out, int ldo, hipStream_t s, float* z_out) {
   if (Cin % 16 || ldo % 4) return SWG_E_SHAPE;
-  Breakup2Args a = {y, g1, b1, g2, b2, out, B * res * res, res, Cin, Cin / 4, ldo};
+  Breakup2Args a = {y, g1, b1, g2, b2, out, B * res * res, res, Cin, Cin / 4, ldo, z_out};
   if (a.rows <= 0) return 0;
   const int cq = ldo / 4;  // chunks to write per quarter
   int lanes = 16;
