@@ -211,8 +211,12 @@ int expand_bwd_impl(const swg_breakup* u, const swg_breakup_train* tr, int B, co
   if ((r = launch_ln_bwd(z, dzn, u->post_ln.g, nullptr, T4, Co, dzn, tr->post_ln.dg, tr->post_ln.db, s))) return r;
   // ---- scatter, norm, pre_linear ----
   // norm backward reads its upstream gradient through the 2x2 gather (dzn is in token layout)
-  if ((r = launch_ln_bwd(y, dzn, u->ln.g, nullptr, T, Cin, dyn, tr->ln.dg, tr->ln.db, s, 2 * u->res, 2))) return r;
-  if ((r = launch_cast_pad(dyn, T, Cin, Cin, dyb2, Kp, s))) return r;
+  if (Kp == Cin) {  // ... and writes it as the bf16 GEMM operand directly (no fp32 copy, no cast pass)
+    if ((r = launch_ln_bwd(y, dzn, u->ln.g, nullptr, T, Cin, nullptr, tr->ln.dg, tr->ln.db, s, 2 * u->res, 2, dyb2))) return r;
+  } else {
+    if ((r = launch_ln_bwd(y, dzn, u->ln.g, nullptr, T, Cin, dyn, tr->ln.dg, tr->ln.db, s, 2 * u->res, 2))) return r;
+    if ((r = launch_cast_pad(dyn, T, Cin, Cin, dyb2, Kp, s))) return r;
+  }
   const bf16* wt = (const bf16*)tr->pre.wt;  // [Cin (input feature), Kp]: rows [0, Cin/2) belong to x, the rest to skip
   GemmEpi e2 = {};
   e2.out_f32 = dx; e2.ldo = Cin / 2;

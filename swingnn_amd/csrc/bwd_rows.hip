@@ -177,7 +177,8 @@ template <int V>
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                 const float* __restrict__ g, const float* __restrict__ dres, int rows,
                                                 int C, float* __restrict__ dx, float* __restrict__ dg,
-                                                float* __restrict__ db, int perm_res, int perm_mask) {
+                                                float* __restrict__ db, int perm_res, int perm_mask,
+                                                bf16* __restrict__ dxb) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int nch = C >> 2;
@@ -249,7 +250,8 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
           const float4 r = *reinterpret_cast<const float4*>(dres + (size_t)row * C + 4 * c);
           o.x += r.x; o.y += r.y; o.z += r.z; o.w += r.w;
         }
-        *reinterpret_cast<float4*>(dx + ((perm_mask & 4) ? po[i] : (size_t)row * C + 4 * c)) = o;
+        if (dxb) *reinterpret_cast<uint2*>(dxb + (size_t)row * C + 4 * c) = pack_bf16x4(o.x, o.y, o.z, o.w);
+        else *reinterpret_cast<float4*>(dx + ((perm_mask & 4) ? po[i] : (size_t)row * C + 4 * c)) = o;
       }
     }
   }
@@ -667,9 +669,10 @@ int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, bf16* a_out,
 }
 
 int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
-                  float* dg, float* db, hipStream_t s, int perm_res, int perm_mask) {
+                  float* dg, float* db, hipStream_t s, int perm_res, int perm_mask, bf16* dx_bf16) {
   if (rows <= 0) return 0;
   if (C % 4 || C > 3072) return SWG_E_UNSUPPORTED;
+  if (dx_bf16) dx = reinterpret_cast<float*>(dx_bf16);  // bf16 [rows, C] INSTEAD of the fp32 output (GEMM operand)
   if (perm_res && (C % 16 || perm_res % 2 || dres)) return SWG_E_SHAPE;
   if (!perm_res) perm_mask = 0;
   if (!x || !dy || !g || !dx || !dg || !db) return SWG_E_NULL;
@@ -678,7 +681,7 @@ int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* 
   const size_t lds = (size_t)2 * C * sizeof(float);
   SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)rows * C * (dres ? 16.0 : 12.0), s);
 #define LNB(VV) \
-  hipLaunchKernelGGL((k_ln_bwd<VV>), dim3(grid), dim3(256), lds, s, x, dy, g, dres, rows, C, dx, dg, db, perm_res, perm_mask)
+  hipLaunchKernelGGL((k_ln_bwd<VV>), dim3(grid), dim3(256), lds, s, x, dy, g, dres, rows, C, dx, dg, db, perm_res, perm_mask, dx_bf16)
   if (V <= 1) LNB(1);
   else if (V == 2) LNB(2);
   else if (V == 3) LNB(3);

@@ -252,7 +252,8 @@ int launch_ln_cond_bwd(const float* x, const float* dxn, const float* dres, cons
 int launch_gelu_bwd_colsum(const bf16* h, const bf16* da, bf16* dh, bf16* a_out, int rows, int N, int ld, float* db,
                            hipStream_t s);
 int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* dres, int rows, int C, float* dx,
-                  float* dg, float* db, hipStream_t s, int perm_res = 0, int perm_mask = 0);
+                  float* dg, float* db, hipStream_t s, int perm_res = 0, int perm_mask = 0,
+                  bf16* dx_bf16 = nullptr);
 int launch_cond_bwd(const float* x, const float* dxc, const float* cond, int cond_stride, int cond_off, int B, int L, int C,
                     float* dx, float* dcond, int dcond_stride, hipStream_t s);
 int launch_perm22(const float* src, float* dst, int B, int res, int C, int dir, hipStream_t s);
