@@ -277,6 +277,10 @@ typedef struct swg_block_train {
   swg_ln_train ln1, ln2;
   swg_lin_train qkv, proj, fc1, fc2;
   float* drpb; /* [(2win-1)^2, heads] */
+  /* optional derived cache for the fused front half of the MLP backward (C = 96, 192): per 64-wide hidden chunk the
+   * fc1 rows and the fc2^T rows in the LDS row layout of mlp_img (swingnn_amd/engine.py mlp_bwd_front_image).
+   * NULL -> LayerNorm, fc1 GEMM, cast, fc2^T GEMM and the GELU pass run as separate kernels. */
+  const void* mlp_bwd_img;
 } swg_block_train;
 typedef struct swg_merge_train {
   swg_ln_train ln;

@@ -72,7 +72,7 @@ class SwgLnTrain(C.Structure):
 
 class SwgBlockTrain(C.Structure):
     _fields_ = [("ln1", SwgLnTrain), ("ln2", SwgLnTrain), ("qkv", SwgLinTrain), ("proj", SwgLinTrain),
-                ("fc1", SwgLinTrain), ("fc2", SwgLinTrain), ("drpb", _fp)]
+                ("fc1", SwgLinTrain), ("fc2", SwgLinTrain), ("drpb", _fp), ("mlp_bwd_img", _fp)]
 
 
 class SwgMergeTrain(C.Structure):

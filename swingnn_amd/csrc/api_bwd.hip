@@ -127,24 +127,37 @@ int mlp_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const f
   bf16* dyb = cv.take<bf16>((size_t)T * Cp);
   bf16* da = cv.take<bf16>((size_t)T * Hp);
   float* dxn = cv.take<float>((size_t)T * C);
+  const bool front = tr && tr->mlp_bwd_img && mlp_bwd_front_supported(C) && Cp == C && Hp == H;
+  float* part = cv.take<float>(mlp_bwd_front_supported(C) ? mlp_bwd_front_part_floats(C, T) : 0);
   WgradScratch w = take_wgrad(cv, H, H, T);
   if (cv.measure) return 0;
   if (!cv.ok) return SWG_E_WORKSPACE;
   int r;
   if ((r = check_lin_train(tr->fc1, true)) || (r = check_lin_train(tr->fc2, true))) return r;
   if (!tr->ln2.dg || !tr->ln2.db) return SWG_E_NULL;
-  // ---- recompute (:275, :19-25) ----
-  if ((r = launch_cond_ln(x_in, T, C, L, nullptr, 0, 0, blk->ln2.g, blk->ln2.b, nullptr, xn, Cp, s))) return r;
-  GemmEpi e = {};
-  e.bias = blk->fc1.b; e.out_bf16 = h; e.ldo = Hp; e.n_store = Hp;
-  if ((r = launch_gemm(xn, Cp, (const bf16*)blk->fc1.w, T, H, Cp, e, s))) return r;
-  // ---- fc2: da = dy W2 ----
-  if ((r = launch_cast_pad_colsum(dy, T, C, C, dyb, Cp, tr->fc2.db, s))) return r;
-  GemmEpi e1 = {};
-  e1.out_bf16 = da; e1.ldo = Hp; e1.n_store = Hp;
-  if ((r = launch_gemm(dyb, Cp, (const bf16*)tr->fc2.wt, T, H, Cp, e1, s))) return r;
-  // ---- GELU: one pass over h gives the activation a = gelu(h) (operand of dW2) and dh = da gelu'(h) (+ db1) ----
-  if ((r = launch_gelu_bwd_colsum(h, da, da, a, T, H, Hp, tr->fc1.db, s))) return r;
+  if (front) {
+    // ---- narrow stages: LayerNorm2, fc1, GELU, dy W2 and GELU' in one pass; h and da stay in registers; the bias
+    // gradients come out as per-workgroup column sums, folded by two small column-sum launches ----
+    if ((r = launch_mlp_bwd_front(C, T, x_in, dy, (const bf16*)tr->mlp_bwd_img, blk->fc1.b, blk->ln2.g, blk->ln2.b, xn, dyb,
+                                  Cp, a, da, Hp, part, s)))
+      return r;
+    const int nwg = cdiv(T, 128);
+    if ((r = launch_colsum_f32(part, nwg, H, 5 * C, tr->fc1.db, s))) return r;
+    if ((r = launch_colsum_f32(part + H, nwg, C, 5 * C, tr->fc2.db, s))) return r;
+  } else {
+    // ---- recompute (:275, :19-25) ----
+    if ((r = launch_cond_ln(x_in, T, C, L, nullptr, 0, 0, blk->ln2.g, blk->ln2.b, nullptr, xn, Cp, s))) return r;
+    GemmEpi e = {};
+    e.bias = blk->fc1.b; e.out_bf16 = h; e.ldo = Hp; e.n_store = Hp;
+    if ((r = launch_gemm(xn, Cp, (const bf16*)blk->fc1.w, T, H, Cp, e, s))) return r;
+    // ---- fc2: da = dy W2 ----
+    if ((r = launch_cast_pad_colsum(dy, T, C, C, dyb, Cp, tr->fc2.db, s))) return r;
+    GemmEpi e1 = {};
+    e1.out_bf16 = da; e1.ldo = Hp; e1.n_store = Hp;
+    if ((r = launch_gemm(dyb, Cp, (const bf16*)tr->fc2.wt, T, H, Cp, e1, s))) return r;
+    // ---- GELU: one pass over h gives the activation a = gelu(h) (operand of dW2) and dh = da gelu'(h) (+ db1) ----
+    if ((r = launch_gelu_bwd_colsum(h, da, da, a, T, H, Hp, tr->fc1.db, s))) return r;
+  }
   if ((r = wgrad_tn(dyb, Cp, C, a, Hp, H, T, tr->fc2.dw, w, s))) return r;
   // ---- fc1 ----
   GemmEpi e2 = {};

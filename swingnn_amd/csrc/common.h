@@ -81,6 +81,15 @@ __device__ __forceinline__ float rows_sum(float v) {
   auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   return __uint_as_float(b[0]) + __uint_as_float(b[1]);
 }
+// sum over the 16 lanes of a DPP row (lanes 16k .. 16k+15: the 16 tokens of a lane group in the token-on-lane layouts):
+// four v_add with a row-rotate DPP modifier, no LDS crossbar.  Every lane ends with the total.
+__device__ __forceinline__ float row16_sum(float v) {
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+  v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+  return v;
+}
 __device__ __forceinline__ float rows_max(float v) {
   auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
   v = __builtin_fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
@@ -245,6 +254,11 @@ int launch_colsum_bf16(const bf16* src, int M, int N, int ld, float* out, hipStr
 int launch_gelu_fwd(const bf16* h, bf16* a, size_t n, hipStream_t s);
 int launch_gelu_bwd(const bf16* h, const bf16* da, bf16* dh, size_t n, hipStream_t s);
 int launch_cast_pad_colsum(const float* x, int rows, int C, int ldx, bf16* out, int ldo, float* db, hipStream_t s);
+bool mlp_bwd_front_supported(int C);
+int launch_mlp_bwd_front(int C, int T, const float* x, const float* dy, const bf16* img, const float* b1, const float* g,
+                         const float* b, bf16* xn, bf16* dyb, int ldc, bf16* act, bf16* dh, int ldh, float* part,
+                         hipStream_t s);
+size_t mlp_bwd_front_part_floats(int C, int T);
 bool ln_cond_bwd_supported(int C);
 int launch_ln_cond_bwd(const float* x, const float* dxn, const float* dres, const float* g, const float* cond,
                        int cond_stride, int cond_off, int B, int L, int C, float* dx, float* dg, float* db, float* dcond,

@@ -207,6 +207,24 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch
     return torch.cat([a, b], dim=1).to(dtype).contiguous()
 
 
+MLP_BWD_FRONT_HC = {96: 64, 192: 32}   # hidden chunk width of csrc/mlp_bwd_front.hip per channel count
+
+
+def mlp_bwd_front_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    """Weight image of csrc/mlp_bwd_front.hip: per hidden chunk of hcw features the fc1 rows [hcw, C] and the fc2^T
+    rows [hcw, C], each as [k-step][row][4 slots][8] in the swizzled LDS row layout of mlp_image."""
+    w1, w2t = w1.detach().float(), w2.detach().float().t().contiguous()
+    H, Cdim = w1.shape
+    hcw = MLP_BWD_FRONT_HC[Cdim]
+    nch, ks = H // hcw, Cdim // 32
+    parts = []
+    for w in (w1, w2t):
+        a = w.reshape(nch, hcw, ks, 4, 8).permute(0, 2, 1, 3, 4)              # [hc, s, r, ch, e]
+        parts.append(_slot_swizzle(a.contiguous()).reshape(nch, -1))
+    return torch.cat(parts, dim=1).to(dtype).contiguous()
+
+
+MLP_BWD_FRONT_DIMS = (96, 192)   # channel counts with the fused front half of the MLP backward
 STREAM_MLP_HC = {384: 32, 192: 32}  # hidden chunk width of csrc/mlp_stream.hip per channel count
 
 

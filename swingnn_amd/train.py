@@ -52,6 +52,16 @@ class TrainCache:
             if p.dim() == 2 and name.endswith("weight") and ".affine." not in name and "map_layer" not in name:
                 self.wt[name] = _wt(p)
                 registry.append(("padT", (p,), self.wt[name], None))
+        # fused front half of the MLP backward (csrc/mlp_bwd_front.hip): one weight image per narrow block
+        self.mlp_bwd_img = {}
+        keep = E.Keep(registry)
+        self._keep = keep
+        for lname, layer in [(f"down_layers.{i}", l) for i, l in enumerate(model.down_layers)] + \
+                            [(f"up_layers.{i}", l) for i, l in enumerate(model.up_layers)]:
+            for j, blk in enumerate(layer.blocks):
+                if blk.dim in E.MLP_BWD_FRONT_DIMS:
+                    self.mlp_bwd_img[f"{lname}.blocks.{j}"] = keep.image(E.mlp_bwd_front_image,
+                                                                        (blk.mlp.fc1.weight, blk.mlp.fc2.weight))
         pe = model.patch_embed
         self.pe_wb = _padded_bf16(pe.proj.weight.detach().reshape(model.embed_dim, -1))
         registry.append(("pad", (pe.proj.weight,), self.pe_wb, None))
@@ -323,7 +333,8 @@ def _trunk_backward(cache, tc, book, names, saved, dcur, cond, ct, dcond, B, wp,
             tr = L.SwgBlockTrain(_ln_train(book, pre + ".norm1"), _ln_train(book, pre + ".norm2"),
                                  _lin_train(tc, book, pre + ".attn.qkv"), _lin_train(tc, book, pre + ".attn.proj"),
                                  _lin_train(tc, book, pre + ".mlp.fc1"), _lin_train(tc, book, pre + ".mlp.fc2"),
-                                 book.ptr(pre + ".attn.relative_position_bias_table"))
+                                 book.ptr(pre + ".attn.relative_position_bias_table"),
+                                 E._ptr(tc.mlp_bwd_img.get(pre)))
             blk = C.byref(ly.blocks[j])
             dmid = torch.empty_like(mid)
             _run(L.lib.swg_ln_mlp_bwd, "swg_ln_mlp_bwd", blk, _c(tr), B, mid.data_ptr(), dcur.data_ptr(), dmid.data_ptr(),
