@@ -57,9 +57,10 @@ int wgrad(const float* dy_f32, const bf16* dy_b, int ldy, int N, const bf16* xb,
 }
 
 // dW[N,K] += dY^T X on the token-major operands themselves (k_gemm_tn): dY bf16 [rows, ldy], X bf16 [rows, ldx]
+// db (optional): the bias gradient db[n] += sum_rows dy[., n] as a by-product of the same pass over dy
 int wgrad_tn(const bf16* dy_b, int ldy, int N, const bf16* xb, int ldx, int K, int rows, float* dw, const WgradScratch& w,
-             hipStream_t s) {
-  return launch_gemm_tn_splitk(dy_b, ldy, xb, ldx, rows, N, K, dw, w.partial, w.partial_floats, s);
+             hipStream_t s, float* db = nullptr) {
+  return launch_gemm_tn_splitk(dy_b, ldy, xb, ldx, rows, N, K, dw, w.partial, w.partial_floats, s, db);
 }
 
 int check_lin_train(const swg_lin_train& t, bool bias) {
@@ -106,8 +107,7 @@ int wattn_bwd_impl(const swg_block* blk, const swg_block_train* tr, int B, const
   GemmEpi e2 = {};
   e2.out_f32 = dxn; e2.ldo = C;
   if ((r = launch_gemm(dqkv, Q3p, (const bf16*)tr->qkv.wt, T, C, Q3p, e2, s))) return r;
-  if ((r = wgrad_tn(dqkv, Q3p, 3 * C, xn, Cp, C, T, tr->qkv.dw, w, s))) return r;
-  if ((r = launch_colsum_bf16(dqkv, T, 3 * C, Q3p, tr->qkv.db, s))) return r;
+  if ((r = wgrad_tn(dqkv, Q3p, 3 * C, xn, Cp, C, T, tr->qkv.dw, w, s, tr->qkv.db))) return r;  // + qkv bias gradient
   // ---- LN1 + shortcut (:241-244, :272) and conditioning (:238-240) in one pass; the shortcut x1 is recomputed ----
   if (fused_tail)
     return launch_ln_cond_bwd(x_in, dxn, dy, blk->ln1.g, cond, cond_stride, blk->cond_off, B, L, C, dx, tr->ln1.dg,

@@ -244,7 +244,7 @@ int launch_gemm_splitk(const bf16* A, int lda, const bf16* W, int ldw, int M, in
                        size_t partial_floats, hipStream_t s);
 // weight-gradient form on token-major operands (no transposed copies): out[Mo,No] += sum_t P[t,m] Q[t,n]
 int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int rows, int Mo, int No, float* out,
-                          float* partial, size_t partial_floats, hipStream_t s);
+                          float* partial, size_t partial_floats, hipStream_t s, float* colsum_p = nullptr);
 // bwd_rows.hip : memory-bound kernels of the backward pass
 int launch_cast_pad(const float* x, int rows, int C, int ldx, bf16* out, int ldo, hipStream_t s);
 int launch_transpose_f32(const float* src, int M, int N, int ld, bf16* dst, int ldd, hipStream_t s);

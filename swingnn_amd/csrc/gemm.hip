@@ -335,7 +335,7 @@ constexpr int TD_STAGE = 2 * TD_OP;         // P tile then Q tile
 __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ P, int ldp, const bf16* __restrict__ Q,
                                                         int ldq, int rows, int Mo, int No, float* __restrict__ out,
                                                         int tiles_n, int tiles, int nslices, int kslice, size_t out_slice,
-                                                        int accumulate) {
+                                                        int accumulate, float* __restrict__ colsum_p) {
   __shared__ __attribute__((aligned(1024))) bf16 sm[TD_NBUF * TD_STAGE];
   const int xcd = blockIdx.x & 7, slot = blockIdx.x >> 3;
   const int sl = xcd + 8 * (slot / tiles);
@@ -377,6 +377,15 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ P, 
   for (int i = 0; i < 4; ++i)
 #pragma unroll
     for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  // optional by-product: colsum_p[m] += sum_t P[t, m] (the bias gradient of the same layer) as one more MFMA per row
+  // tile against an all-ones operand, by the tn == 0 workgroups' wn == 0 waves (every column of the result is the sum)
+  const bool do_colsum = colsum_p != nullptr && tn == 0 && wn == 0;
+  f32x4 accb[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) accb[i] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  bf16x8 ones;
+#pragma unroll
+  for (int e = 0; e < 8; ++e) ones[e] = (bf16)1.0f;
 
   // transposed-read element offsets inside an operand tile, per 16-column block t and half (rows 4 lg + q, 16 + ...)
   int offa[4], offb[4];
@@ -433,9 +442,22 @@ __global__ __launch_bounds__(256, 2) void k_gemm_tn(const bf16* __restrict__ P, 
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
         acc[mt][nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], fb[nt], acc[mt][nt], 0, 0, 0);
+    if (do_colsum) {
+#pragma unroll
+      for (int mt = 0; mt < 4; ++mt) accb[mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fa[mt], ones, accb[mt], 0, 0, 0);
+    }
     buf = buf == TD_NBUF - 1 ? 0 : buf + 1;
   }
 #undef TD_ISSUE
+  if (do_colsum && l15 == 0) {
+#pragma unroll
+    for (int mt = 0; mt < 4; ++mt)
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int m = m0 + wm * 64 + mt * 16 + 4 * lg + r;
+        if (m < Mo) unsafeAtomicAdd(colsum_p + m, accb[mt][r]);
+      }
+  }
 #pragma unroll
   for (int mt = 0; mt < 4; ++mt)
 #pragma unroll
@@ -507,7 +529,7 @@ int launch_gemm_splitk(const bf16* A, int lda, const bf16* W, int ldw, int M, in
 }
 
 int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int rows, int Mo, int No, float* out,
-                          float* partial, size_t partial_floats, hipStream_t s) {
+                          float* partial, size_t partial_floats, hipStream_t s, float* colsum_p) {
   if (rows <= 0 || Mo <= 0 || No <= 0) return 0;
   if (ldp % 8 || ldq % 8 || No % 4 || ldp < 8 || ldq < 8) return SWG_E_SHAPE;
   if (!P || !Q || !out) return SWG_E_NULL;
@@ -520,14 +542,14 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
                                                            8.0 * Mo * (double)No, s);
   if (S <= 1) {
     hipLaunchKernelGGL(k_gemm_tn, dim3(8 * tiles), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n, tiles, 1, kslice,
-                       (size_t)0, 1);
+                       (size_t)0, 1, colsum_p);
     SWG_LAUNCH_CHECK();
     return 0;
   }
   // the S token slices add their tiles into `out` with fp32 atomics: no partial buffers, no reduction pass (the other
   // parameter-gradient kernels accumulate with atomics too; the summation order across slices is not fixed)
   hipLaunchKernelGGL(k_gemm_tn, dim3(tiles * round_up(S, 8)), dim3(256), 0, s, P, ldp, Q, ldq, rows, Mo, No, out, tiles_n,
-                     tiles, S, kslice, (size_t)0, 2);
+                     tiles, S, kslice, (size_t)0, 2, colsum_p);
   SWG_LAUNCH_CHECK();
   return 0;
 }
