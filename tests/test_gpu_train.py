@@ -319,3 +319,33 @@ def test_gradient_sync_sends_only_finished_slices(golden_meta, name, monkeypatch
     for k, g in plain.items():
         scale = float(g.abs().max()) + 1e-30
         assert float((synced[k] - g).abs().max()) <= 1e-5 * scale, k
+
+
+def test_mlp_backward_front_kernel_matches_unfused_chain(golden_meta, monkeypatch):
+    """C = 96 / 192 blocks run the front half of the MLP backward as one kernel (mlp_bwd_front.hip).  With the weight
+    images withheld the same step takes the unfused chain (LayerNorm, fc1 GEMM, cast, fc2^T GEMM, GELU pass): the two
+    must give the same gradients up to the bf16 rounding of h, which only the unfused chain stores."""
+    import swingnn_amd as S
+    from swingnn_amd import engine as E, train as T
+    from tests.test_gpu_parity import build_precond
+    c = NET_CASES["grid192"]
+    flags, x, sig, w, clean = (t.to(DEV) for t in H.train_case_inputs(c, 1))
+    loss_fn = S.RainbowLoss(1.0, False, "edm")
+    monkeypatch.setattr(np.random, "rand", lambda: 0.75)
+
+    def grads(fused):
+        pre = build_precond(S, "grid192", golden_meta, "init").train()
+        tc = T.get_train_cache(pre.model, E.get_cache(pre.model))
+        assert any(k for k in tc.mlp_bwd_img), "grid192 has C = 96 and C = 192 blocks"
+        if not fused:
+            tc.mlp_bwd_img = {}
+        with torch.enable_grad():
+            D = pre(x=x, node_flags=flags, sigmas=sig)
+            loss_fn(D, clean, sig, x, clean, flags, loss_weight=w, reduction='none').mean().backward()
+        return {k: p.grad.detach().clone() for k, p in pre.named_parameters()}
+
+    a, b = grads(True), grads(False)
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in b.values())))
+    for k in b:
+        rel = float((a[k] - b[k]).norm()) / max(float(b[k].norm()), 1e-3 * total)
+        assert rel <= 2e-2, (k, rel)
