@@ -29,18 +29,20 @@ __device__ __forceinline__ void split_bf16(const float (&f)[8], bf16x8& hi, bf16
   }
 }
 
-// channel held by accumulator row i of output tile nt (the rho order of engine.py): a lane's rows 4*lg..4*lg+3 of
-// tiles 2k, 2k+1 are 8 consecutive channels -> 32-byte stores per lane, full 128-byte lines per token
-__device__ __forceinline__ int rho_chan(int nt, int i) { return 32 * (nt >> 1) + 8 * (i >> 2) + 4 * (nt & 1) + (i & 3); }
+// channel held by accumulator row i of output tile nt: plain order, so that the four lane groups of one store
+// instruction write 64 contiguous bytes per token (whole 32-byte sectors; the rho order of engine.py, 8 consecutive
+// channels per lane over a tile pair, made every instruction write half sectors 32 bytes apart)
+__device__ __forceinline__ int rho_chan(int nt, int i) { return 16 * nt + i; }
 
 template <int C>
-__global__ __launch_bounds__(256, 4) void k_patch_embed_mfma(EmbedMfmaArgs a) {
+__global__ __launch_bounds__(256, 1) void k_patch_embed_mfma(EmbedMfmaArgs a) {
   constexpr int NT = C / 16;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
   const int kin = a.in_ch * 16;
 
   bf16x8 wh[NT], wl[NT];
+  f32x4 cb[NT];
 #pragma unroll
   for (int nt = 0; nt < NT; ++nt) {
     const int c = rho_chan(nt, l15);
@@ -51,9 +53,8 @@ __global__ __launch_bounds__(256, 4) void k_patch_embed_mfma(EmbedMfmaArgs a) {
       f[e] = (k < kin) ? a.w[c * kin + k] : 0.f;
     }
     split_bf16(f, wh[nt], wl[nt]);
+    cb[nt] = *reinterpret_cast<const f32x4*>(a.bias + rho_chan(nt, 4 * lg));
   }
-  // conv bias, LN weight / bias of this lane's channels are re-read per tile (L1 hits): 72 VGPRs less, which is the
-  // difference between two and four waves per SIMD for this HBM-bound kernel
 
   const int hp = a.N >> 2, L = hp * hp, rows = a.B * L;
   const int ntiles = (rows + 15) >> 4;
@@ -62,29 +63,66 @@ __global__ __launch_bounds__(256, 4) void k_patch_embed_mfma(EmbedMfmaArgs a) {
   const bool has = ci < a.in_ch;
   const bool is_x = (!a.self_cond) || ci == a.in_ch - 1;
   const float* src = is_x ? a.x : a.sc;
-
   const bool live = has && src != nullptr;
-  const int stride_t = gridDim.x * 4;
-  // the taps of the NEXT tile are fetched while the current one is computed (one tile in flight per wave)
-  float4 n0 = make_float4(0.f, 0.f, 0.f, 0.f), n1 = n0;
-  float nsc = 1.0f;
-  auto fetch = [&](int tile) {
-    if (!live || tile >= ntiles) return;
+
+  // Few, long-lived waves (two workgroups per CU), each with a CONTIGUOUS run of tiles: the per-graph epilogue
+  // constants  y = silu(A * xhat + B),  A = g (1 + scale),  B = shift + beta (1 + scale)  then stay in registers and are
+  // reloaded only when a lane's token moves to the next graph.  (Per-tile reloads of scale / shift / g / beta were 30 of
+  // the 45 vector-memory instructions of a tile and kept the address unit as busy as the token stream itself; waves
+  // of 4 tiles paid their start-up -- weight gather, first tap fetch -- once per 4 tiles.)
+  const int nwaves = gridDim.x * 4, gw = blockIdx.x * 4 + wave;
+  const int tpw = (ntiles + nwaves - 1) / nwaves;
+  const int t0 = gw * tpw, t1 = min(ntiles, t0 + tpw);
+  f32x4 cA[NT], cB[NT];
+  int cur_bi = -1;
+  // the taps are fetched D tiles ahead (a load issued after the stores of the previous tile completes after them:
+  // vector-memory operations retire in issue order); D = 1 and D = 4 measured the same, the kernel is bound by its
+  // ~650 instructions per tile with the store issue on top
+  constexpr int D = 2;
+  float4 n0[D], n1[D];
+  float nsc[D];
+  auto fetch = [&](int tile, float4& q0, float4& q1, float& qs) {
+    if (!live || tile >= t1) return;
     const int row = min(tile * 16 + l15, rows - 1);
     const int bi = row / L, rem = row - bi * L;
     const int Y = rem / hp, X = rem - Y * hp;
     const float* p0 = src + ((size_t)bi * a.N + (Y * 4 + ii0)) * a.N + X * 4;
-    n0 = *reinterpret_cast<const float4*>(p0);
-    n1 = *reinterpret_cast<const float4*>(p0 + a.N);
-    nsc = (is_x && a.c_in) ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f;
+    q0 = *reinterpret_cast<const float4*>(p0);
+    q1 = *reinterpret_cast<const float4*>(p0 + a.N);
+    qs = (is_x && a.c_in) ? a.c_in[(size_t)bi * a.c_in_stride] : 1.0f;
   };
-  fetch(blockIdx.x * 4 + wave);
-  for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += stride_t) {
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    n0[d] = make_float4(0.f, 0.f, 0.f, 0.f); n1[d] = n0[d]; nsc[d] = 1.0f;
+    fetch(t0 + d, n0[d], n1[d], nsc[d]);
+  }
+  for (int tb = t0; tb < t1; tb += D)
+#pragma unroll
+  for (int d = 0; d < D; ++d) {
+    const int tile = tb + d;
+    if (tile >= t1) break;
     const int row = min(tile * 16 + l15, rows - 1);
     const int bi = row / L;
-    const float4 r0 = n0, r1 = n1;
-    const float sc = nsc;
-    fetch(tile + stride_t);
+    const float4 r0 = n0[d], r1 = n1[d];
+    const float sc = nsc[d];
+    fetch(tile + D, n0[d], n1[d], nsc[d]);
+    if (bi != cur_bi) {
+      cur_bi = bi;
+      const float* crow = a.cond + (size_t)bi * a.cond_stride + a.cond_off;
+#pragma unroll
+      for (int nt = 0; nt < NT; ++nt) {
+        const int c = rho_chan(nt, 4 * lg);
+        const f32x4 scl = *reinterpret_cast<const f32x4*>(crow + c);
+        const f32x4 sh = *reinterpret_cast<const f32x4*>(crow + C + c);
+        const f32x4 cg = *reinterpret_cast<const f32x4*>(a.g + c);
+        const f32x4 cbeta = *reinterpret_cast<const f32x4*>(a.b + c);
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          cA[nt][r] = cg[r] * (scl[r] + 1.f);
+          cB[nt][r] = sh[r] + cbeta[r] * (scl[r] + 1.f);
+        }
+      }
+    }
     const float f[8] = {sc * r0.x, sc * r0.y, sc * r0.z, sc * r0.w, sc * r1.x, sc * r1.y, sc * r1.z, sc * r1.w};
     bf16x8 xh, xl;
     split_bf16(f, xh, xl);
@@ -92,8 +130,7 @@ __global__ __launch_bounds__(256, 4) void k_patch_embed_mfma(EmbedMfmaArgs a) {
     float s = 0.f;
 #pragma unroll
     for (int nt = 0; nt < NT; ++nt) {
-      const f32x4 cb = *reinterpret_cast<const f32x4*>(a.bias + rho_chan(nt, 4 * lg));
-      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xh, cb, 0, 0, 0);
+      acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xh, cb[nt], 0, 0, 0);
       acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wh[nt], xl, acc[nt], 0, 0, 0);
       acc[nt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(wl[nt], xh, acc[nt], 0, 0, 0);
     }
@@ -109,20 +146,13 @@ __global__ __launch_bounds__(256, 4) void k_patch_embed_mfma(EmbedMfmaArgs a) {
     q = rows_sum(q);
     const float rstd = ln_rstd(q * (1.0f / C));
     if (tile * 16 + l15 < rows) {
-      const float* crow = a.cond + (size_t)bi * a.cond_stride + a.cond_off;
       float* orow = a.tok + (size_t)row * C;
 #pragma unroll
       for (int nt = 0; nt < NT; ++nt) {
-        const int c = rho_chan(nt, 4 * lg);
-        const f32x4 sc = *reinterpret_cast<const f32x4*>(crow + c);
-        const f32x4 sh = *reinterpret_cast<const f32x4*>(crow + C + c);
-        const f32x4 cg = *reinterpret_cast<const f32x4*>(a.g + c);
-        const f32x4 cbeta = *reinterpret_cast<const f32x4*>(a.b + c);
         f32x4 y;
 #pragma unroll
-        for (int r = 0; r < 4; ++r)
-          y[r] = silu_f(sh[r] + ((acc[nt][r] - mean) * rstd * cg[r] + cbeta[r]) * (sc[r] + 1.f));
-        *reinterpret_cast<f32x4*>(orow + c) = y;
+        for (int r = 0; r < 4; ++r) y[r] = silu_f(cB[nt][r] + ((acc[nt][r] - mean) * rstd) * cA[nt][r]);
+        *reinterpret_cast<f32x4*>(orow + rho_chan(nt, 4 * lg)) = y;
       }
     }
   }
@@ -223,6 +253,13 @@ __global__ __launch_bounds__(256, 2) void k_breakup_post(BreakupPostArgs a) {
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
       wf[nt][ks] = *reinterpret_cast<const bf16x8*>(a.w + (size_t)rho_chan(nt, l15) * a.ldw + 32 * ks + 8 * lg);
+  // the affine parameters of both LayerNorms (2 * Cin + 2 * Co floats) are read from LDS: as global loads they were 96
+  // of a tile's 144 vector-memory instructions
+  __shared__ __align__(16) float cst[2 * CIN + 2 * CO];
+  for (int i = threadIdx.x; i < CIN; i += 256) { cst[i] = a.g1[i]; cst[CIN + i] = a.b1[i]; }
+  for (int i = threadIdx.x; i < CO; i += 256) { cst[2 * CIN + i] = a.g2[i]; cst[2 * CIN + CO + i] = a.b2[i]; }
+  __syncthreads();
+  const int cst_lane = 8 * lg;
   const int ntiles = (a.rows + 15) >> 4;
   const int L = a.res * a.res;
   for (int tile = blockIdx.x * 4 + wave; tile < ntiles; tile += gridDim.x * 4) {
@@ -252,14 +289,19 @@ __global__ __launch_bounds__(256, 2) void k_breakup_post(BreakupPostArgs a) {
     const int yy = rem / a.res, xx = rem - yy * a.res;
 #pragma unroll
     for (int k = 0; k < 4; ++k) {
+      // (an opaque offset per quarter keeps the compiler from hoisting all 240 loop-invariant LDS reads into registers)
+      int zoff = cst_lane;
+      asm volatile("" : "+v"(zoff));
+      const float* lg1 = cst + zoff; const float* lb1 = cst + CIN + zoff;
+      const float* lg2 = cst + 2 * CIN + zoff; const float* lb2 = cst + 2 * CIN + CO + zoff;
       // norm (its affine parameters are indexed by the position in the Cin row), then the sub-vector statistics
       float s2 = 0.f;
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.g1 + k * CO + 32 * ks + 8 * lg);
-        const f32x4 gb = *reinterpret_cast<const f32x4*>(a.g1 + k * CO + 32 * ks + 8 * lg + 4);
-        const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b1 + k * CO + 32 * ks + 8 * lg);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b1 + k * CO + 32 * ks + 8 * lg + 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(lg1 + k * CO + 32 * ks);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(lg1 + k * CO + 32 * ks + 4);
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(lb1 + k * CO + 32 * ks);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(lb1 + k * CO + 32 * ks + 4);
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           v[k][ks][e] = (v[k][ks][e] - mean) * rstd * ga[e] + ba[e];
@@ -279,10 +321,10 @@ __global__ __launch_bounds__(256, 2) void k_breakup_post(BreakupPostArgs a) {
       for (int nt = 0; nt < NT; ++nt) acc[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
-        const f32x4 ga = *reinterpret_cast<const f32x4*>(a.g2 + 32 * ks + 8 * lg);
-        const f32x4 gb = *reinterpret_cast<const f32x4*>(a.g2 + 32 * ks + 8 * lg + 4);
-        const f32x4 ba = *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg);
-        const f32x4 bb = *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg + 4);
+        const f32x4 ga = *reinterpret_cast<const f32x4*>(lg2 + 32 * ks);
+        const f32x4 gb = *reinterpret_cast<const f32x4*>(lg2 + 32 * ks + 4);
+        const f32x4 ba = *reinterpret_cast<const f32x4*>(lb2 + 32 * ks);
+        const f32x4 bb = *reinterpret_cast<const f32x4*>(lb2 + 32 * ks + 4);
         bf16x8 f;
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
@@ -303,7 +345,7 @@ __global__ __launch_bounds__(256, 2) void k_breakup_post(BreakupPostArgs a) {
   }
 }
 
-int persistent_grid(int ntiles) { return max(1, min(cdiv(ntiles, 4), 256 * 8)); }
+int persistent_grid(int ntiles, int g = 8) { return max(1, min(cdiv(ntiles, 4), 256 * g)); }
 
 }  // namespace
 
@@ -318,7 +360,8 @@ int launch_patch_embed_mfma(const swg_net* net, int B, const float* x, const flo
   const int hp = net->N / 4, rows = B * hp * hp;
   SwgProfScope ps(KID_PATCH_EMBED, 2.0 * rows * 96.0 * 16 * net->in_ch,
                   4.0 * B * (double)net->N * net->N * (sc ? 2 : 1) + 4.0 * rows * 96.0, s);
-  hipLaunchKernelGGL((k_patch_embed_mfma<96>), dim3(persistent_grid(cdiv(rows, 16))), dim3(256), 0, s, a);
+  // one workgroup per CU (measured: 105 us per launch of 56 graphs with 8 short-lived workgroups per CU, 75 us with one)
+  hipLaunchKernelGGL((k_patch_embed_mfma<96>), dim3(persistent_grid(cdiv(rows, 16), 1)), dim3(256), 0, s, a);
   SWG_LAUNCH_CHECK();
   return 0;
 }
