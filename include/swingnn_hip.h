@@ -70,6 +70,9 @@ typedef struct swg_merge {
   int32_t C, res;
   swg_ln ln;   /* LayerNorm(4C) */
   swg_lin red; /* Linear(4C -> 2C), no bias */
+  /* optional weight image of the fused kernel (C = 96 / 192; swingnn_amd/engine.py merge_image): gather, LayerNorm and
+   * the reduction then run as one pass over the fp32 rows.  NULL -> LayerNorm pass + GEMM. */
+  const void* img;
 } swg_merge;
 
 /* PatchBreakup (:347-403) at input resolution res x res, input width Cin = 4C' */

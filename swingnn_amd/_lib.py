@@ -33,7 +33,7 @@ class SwgBlock(C.Structure):
 
 
 class SwgMerge(C.Structure):
-    _fields_ = [("C", C.c_int32), ("res", C.c_int32), ("ln", SwgLn), ("red", SwgLin)]
+    _fields_ = [("C", C.c_int32), ("res", C.c_int32), ("ln", SwgLn), ("red", SwgLin), ("img", C.c_void_p)]
 
 
 class SwgBreakup(C.Structure):

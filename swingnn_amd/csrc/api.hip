@@ -164,6 +164,10 @@ int merge_impl(const swg_merge* m, int B, const float* x_in, float* x_out, void*
   int r;
   if ((r = check_lin(m->red, 2 * m->C, 4 * m->C))) return r;
   const int T4 = B * (m->res / 2) * (m->res / 2), Kp = kp(4 * m->C);
+  // one pass for the narrow stages; a workgroup takes 128 merged tokens and streams the whole weight, so small token
+  // counts stay on the GEMM
+  if (m->img && merge_fused_supported(m->C, m->res) && T4 >= 16384)
+    return launch_merge_fused(m->C, B, m->res, x_in, (const bf16*)m->img, m->ln.g, m->ln.b, x_out, s);
   Carver cv(ws, ws_bytes);
   bf16* xn = cv.take<bf16>((size_t)T4 * Kp);
   if (!cv.ok) return SWG_E_WORKSPACE;

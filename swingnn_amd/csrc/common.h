@@ -306,6 +306,10 @@ int launch_breakup_post(const float* y, int B, int res, int Co, const float* g1,
 bool mlp_fused_supported(int C);
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                      const float* g, const float* b, hipStream_t s);
+// merge_fused.hip : PatchMerging (2x2 gather + LayerNorm(4C) + Linear(4C -> 2C)) in one pass, C = 96 / 192
+bool merge_fused_supported(int C, int res);
+int launch_merge_fused(int C, int B, int res, const float* x, const bf16* img, const float* g, const float* b, float* out,
+                       hipStream_t s);
 // mlp_stream.hip : the same for the wide stages (C = 384), LDS ring + skewed GELU pipeline, fragment-order image
 bool mlp_stream_supported(int C);
 bool mlp_stream_proj_supported(int C);

@@ -36,6 +36,7 @@ enum SwgKernelId {
   KID_MLP_STREAM_384,
   KID_WATTN_RING_384,
   KID_MLP_PROJ_384,
+  KID_MERGE_FUSED,
   KID_COUNT
 };
 

@@ -338,8 +338,24 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
                       keep.f32(blk.attn.relative_position_bias_table), img, aimg, pimg)
 
 
+MERGE_FUSED_NC = {96: 32, 192: 16}   # output features per 24-KiB weight chunk of csrc/merge_fused.hip, per input width
+
+
+def merge_image(w: torch.Tensor, nc: int, dtype=torch.bfloat16) -> torch.Tensor:
+    """Weight image of csrc/merge_fused.hip: the reduction weight [2C, 4C] in MFMA fragment order (1 KiB per fragment,
+    lane 16*lg + i holds row i, k-slots 8*lg .. 8*lg+7), chunk c = output features [c*nc, (c+1)*nc) as fragments
+    (k-step, 16-row output tile), k-step major."""
+    w = w.detach().float()
+    N, K = w.shape
+    a = w.reshape(N // nc, nc // 16, 16, K // 32, 4, 8).permute(0, 3, 1, 4, 2, 5)   # [chunk, ks, ht, lg, i, e]
+    return a.reshape(-1).to(dtype).contiguous()
+
+
 def merge_desc(keep: Keep, m) -> L.SwgMerge:
-    return L.SwgMerge(m.dim, m.input_resolution[0], keep.ln(m.norm), keep.lin(m.reduction.weight))
+    img = None
+    if USE_FUSED_MLP and m.dim in MERGE_FUSED_NC and m.input_resolution[0] % 2 == 0:
+        img = _ptr(keep.image(merge_image, (m.reduction.weight,), MERGE_FUSED_NC[m.dim]))
+    return L.SwgMerge(m.dim, m.input_resolution[0], keep.ln(m.norm), keep.lin(m.reduction.weight), img)
 
 
 def breakup_desc(keep: Keep, u) -> L.SwgBreakup:

@@ -109,6 +109,42 @@ def test_precond_grid384_batched_pass_matches_oracle(monkeypatch):
     assert filt >= 0.999 and raw >= 0.999, (raw, filt)
 
 
+# PatchMerging at token counts where the one-pass kernel (csrc/merge_fused.hip) runs: >= 16384 merged tokens, C = 96 /
+# 192; the reduced golden geometries stay on the LayerNorm pass + GEMM.  Ragged cases: merged token counts that are
+# not a multiple of the 128-token workgroup, odd merged side.
+MERGE_FUSED_CASES = {
+    "c96_r96_b8": dict(C=96, res=96, B=8, seed=71),
+    "c96_r90_b9": dict(C=96, res=90, B=9, seed=72),
+    "c192_r48_b32": dict(C=192, res=48, B=32, seed=73),
+    "c192_r50_b27": dict(C=192, res=50, B=27, seed=74),
+}
+
+
+@pytest.mark.parametrize("name", list(MERGE_FUSED_CASES))
+def test_patch_merging_one_pass_kernel_matches_oracle_and_gemm_path(name):
+    import swingnn_amd as S
+    from swingnn_amd import engine as E
+    c = MERGE_FUSED_CASES[name]
+    sd = H.merge_state(c["C"], c["seed"])
+    m = load(S.PatchMerging((c["res"],) * 2, c["C"]), strip(sd, "m."))
+    x = filler.uniform("x", (c["B"], c["res"] ** 2, c["C"]), c["seed"])
+    assert c["B"] * (c["res"] // 2) ** 2 >= 16384 and c["C"] in E.MERGE_FUSED_NC
+    out = m(x.to(DEV)).cpu()
+    ref = O.patch_merging(x, sd, "m", c["res"])
+    rel_close(out, ref)
+    saved = E.USE_FUSED_MLP
+    E.USE_FUSED_MLP = False          # no weight image in the descriptor: LayerNorm pass + GEMM
+    try:
+        out2 = m(x.to(DEV)).cpu()
+    finally:
+        E.USE_FUSED_MLP = saved
+    rel_close(out2, ref)
+    # both round the same LayerNorm output to bf16 and accumulate in fp32: they differ by summation order only
+    d = (out - out2).abs()
+    scale = float(ref.abs().max())
+    assert float(d.max()) <= 2e-3 * scale and float(d.mean()) <= 5e-5 * scale, (float(d.max()), float(d.mean()), scale)
+
+
 # C=768 with UN-clamped windows (the last stage of the full-size nets: res 12 / w 6 and res 16 / w 8, 4 windows per
 # graph), which no reduced golden geometry reaches; shifted variants exercise the mask path of that kernel route.
 BIG_BLOCK_CASES = {
