@@ -82,6 +82,12 @@ typedef struct swg_breakup {
   swg_ln ln;      /* LayerNorm(4C') */
   swg_ln post_ln; /* LayerNorm(C')  */
   swg_lin post;   /* Linear(C' -> C'), no bias */
+  /* optional weight images of the one-pass kernel (Cin = 384; swingnn_amd/engine.py merge_image(pre, 32) and
+   * expand_post_image(post)): concat, pre_linear, both LayerNorms, the 2x2 scatter and post_linear then run as one pass
+   * over x and skip (taken only when x_out aliases neither input).  Either NULL -> concat pass, GEMM, breakup tail
+   * kernel(s). */
+  const void* img_pre;
+  const void* img_post;
 } swg_breakup;
 
 /* BasicLayer (:415-483): [upsample] -> blocks -> [downsample] */

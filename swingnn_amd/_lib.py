@@ -38,7 +38,7 @@ class SwgMerge(C.Structure):
 
 class SwgBreakup(C.Structure):
     _fields_ = [("Cin", C.c_int32), ("res", C.c_int32), ("pre", SwgLin), ("ln", SwgLn), ("post_ln", SwgLn),
-                ("post", SwgLin)]
+                ("post", SwgLin), ("img_pre", C.c_void_p), ("img_post", C.c_void_p)]
 
 
 class SwgLayer(C.Structure):

@@ -185,6 +185,12 @@ int expand_impl(const swg_breakup* u, int B, const float* x, const float* skip, 
   int r;
   if ((r = check_lin(u->pre, Cin, Cin))) return r;
   if ((r = check_lin(u->post, Co, Co))) return r;
+  // one pass over x and skip for the last decoder level; a workgroup takes 128 tokens and streams the whole
+  // pre_linear weight, so small token counts stay on the GEMM
+  // (not in place: a workgroup's output rows are other workgroups' input rows)
+  if (u->img_pre && u->img_post && expand_fused_supported(Cin) && T >= 16384 && x_out != x && x_out != skip)
+    return launch_expand_fused(Cin, B, u->res, x, skip, (const bf16*)u->img_pre, (const bf16*)u->img_post, u->ln.g,
+                               u->ln.b, u->post_ln.g, u->post_ln.b, x_out, s);
   Carver cv(ws, ws_bytes);
   bf16* cat = cv.take<bf16>((size_t)T * Kp);
   float* y = cv.take<float>((size_t)T * Cin);
@@ -267,13 +273,14 @@ int plan_net(const swg_net* net, int B, NetPlan* pl) {
   pl->maxTC = maxTC;
   pl->scratch = scratch;
   pl->persistent = align256((size_t)B * 4 * 4) + align256((size_t)B * 4) + align256((size_t)B * net->cond_total * 4) +
-                   align256(maxTC * 4) + skips;
+                   2 * align256(maxTC * 4) + skips;
   return 0;
 }
 
 // persistent buffers of one pass, carved from the caller's workspace; (sw, sb) is the scratch left for the ops
 struct TrunkBufs {
   float *coef, *cnoise, *cond, *A;
+  float* A2;  // second token tensor: PatchBreakup's one-pass kernel cannot run in place
   float* skips[8];
   int Bc, cstride, S;
   void* sw;
@@ -295,6 +302,7 @@ int carve_trunk(const swg_net* net, int B, int labels_uniform, void* ws, size_t 
   tb->cstride = labels_uniform ? 0 : net->cond_total;
   tb->cond = cv.take<float>((size_t)B * net->cond_total);
   tb->A = cv.take<float>(pl.maxTC);
+  tb->A2 = cv.take<float>(pl.maxTC);
   tb->S = S;
   for (int li = 0; li < 8; ++li) tb->skips[li] = nullptr;
   for (int li = 0; li < S; ++li) {
@@ -321,8 +329,9 @@ int run_trunk(const swg_net* net, int B, const TrunkBufs& tb, const float** out,
     if (ly.up) {
       const int si = net->n_layers - 1 - li;  // decoder layer i pops skips[S-1-i], :743
       if (si < 0 || si >= S || !tb.skips[si]) return SWG_E_SHAPE;
-      if ((r = expand_impl(ly.up, B, cur, tb.skips[si], A, tb.sw, tb.sb, s))) return r;
-      cur = A;
+      float* dst = (cur == A) ? tb.A2 : A;
+      if ((r = expand_impl(ly.up, B, cur, tb.skips[si], dst, tb.sw, tb.sb, s))) return r;
+      cur = dst;
     }
     for (int j = 0; j < ly.n_blocks; ++j) {
       const swg_block* blk = &ly.blocks[j];

@@ -310,6 +310,11 @@ int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, 
 bool merge_fused_supported(int C, int res);
 int launch_merge_fused(int C, int B, int res, const float* x, const bf16* img, const float* g, const float* b, float* out,
                        hipStream_t s);
+// expand_fused.hip : concat + PatchBreakup (pre_linear, norm, 2x2 scatter, post_norm, post_linear) in one pass, Cin = 384
+bool expand_fused_supported(int Cin);
+int launch_expand_fused(int Cin, int B, int res, const float* x, const float* skip, const bf16* img_pre,
+                        const bf16* img_post, const float* g1, const float* b1, const float* g2, const float* b2,
+                        float* out, hipStream_t s);
 // mlp_stream.hip : the same for the wide stages (C = 384), LDS ring + skewed GELU pipeline, fragment-order image
 bool mlp_stream_supported(int C);
 bool mlp_stream_proj_supported(int C);

@@ -37,6 +37,7 @@ enum SwgKernelId {
   KID_WATTN_RING_384,
   KID_MLP_PROJ_384,
   KID_MERGE_FUSED,
+  KID_EXPAND_FUSED,
   KID_COUNT
 };
 

@@ -358,9 +358,28 @@ def merge_desc(keep: Keep, m) -> L.SwgMerge:
     return L.SwgMerge(m.dim, m.input_resolution[0], keep.ln(m.norm), keep.lin(m.reduction.weight), img)
 
 
+EXPAND_FUSED_NC = {384: 32, 768: 16}   # output features per 24-KiB pre_linear chunk of csrc/expand_fused.hip, per 4 C'
+EXPAND_FUSED_DIMS = tuple(EXPAND_FUSED_NC)
+
+
+def expand_post_image(w: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
+    """post_linear weight [C', C'] as MFMA fragments for csrc/expand_fused.hip: fragment (k-step s, out tile nt) holds
+    rows nt*16 + i and input columns 32 s + pi(lg, e): the slot order of a pair of stacked accumulator tiles, which the
+    kernel feeds back as the operand."""
+    w = w.detach().float()
+    Co = w.shape[0]
+    wp = w.reshape(Co, Co // 32, 32)[..., _pi(w.device)]                              # [row, s, (lg, e)]
+    a = wp.reshape(Co // 16, 16, Co // 32, 4, 8).permute(2, 0, 3, 1, 4)              # [s, nt, lg, i, e]
+    return a.reshape(-1).to(dtype).contiguous()
+
+
 def breakup_desc(keep: Keep, u) -> L.SwgBreakup:
+    ipre = ipost = None
+    if USE_FUSED_MLP and u.dim in EXPAND_FUSED_DIMS:
+        ipre = _ptr(keep.image(merge_image, (u.pre_linear.weight,), EXPAND_FUSED_NC[u.dim]))
+        ipost = _ptr(keep.image(expand_post_image, (u.post_linear.weight,)))
     return L.SwgBreakup(u.dim, u.input_resolution[0], keep.lin(u.pre_linear.weight), keep.ln(u.norm),
-                        keep.ln(u.post_norm), keep.lin(u.post_linear.weight))
+                        keep.ln(u.post_norm), keep.lin(u.post_linear.weight), ipre, ipost)
 
 
 def collapse_read_out(read_out, p: int):

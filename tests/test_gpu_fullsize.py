@@ -145,6 +145,43 @@ def test_patch_merging_one_pass_kernel_matches_oracle_and_gemm_path(name):
     assert float(d.max()) <= 2e-3 * scale and float(d.mean()) <= 5e-5 * scale, (float(d.max()), float(d.mean()), scale)
 
 
+# PatchBreakup (with the concat of :743) at token counts where the one-pass kernel (csrc/expand_fused.hip) runs:
+# Cin = 384 / 768, >= 16384 input tokens.  Ragged: token count not a multiple of the 128-token workgroup, odd side.
+EXPAND_FUSED_CASES = {
+    "c384_r48_b8": dict(dim=384, res=48, B=8, seed=75),
+    "c384_r45_b9": dict(dim=384, res=45, B=9, seed=76),
+    "c768_r24_b32": dict(dim=768, res=24, B=32, seed=77),
+    "c768_r25_b27": dict(dim=768, res=25, B=27, seed=78),
+}
+
+
+@pytest.mark.parametrize("name", list(EXPAND_FUSED_CASES))
+def test_patch_breakup_one_pass_kernel_matches_oracle_and_gemm_path(name):
+    import swingnn_amd as S
+    from swingnn_amd import engine as E
+    c = EXPAND_FUSED_CASES[name]
+    dim = c["dim"]
+    sd = H.breakup_state(dim, c["seed"])
+    u = load(S.PatchBreakup((c["res"],) * 2, dim), strip(sd, "u."))
+    assert c["B"] * c["res"] ** 2 >= 16384 and dim in E.EXPAND_FUSED_DIMS
+    xb = filler.uniform("xb", (c["B"], c["res"] ** 2, dim), c["seed"])
+    out = u(xb.to(DEV)).cpu()
+    ref = O.patch_breakup(xb, sd, "u", c["res"])
+    rel_close(out, ref)
+    saved = E.USE_FUSED_MLP
+    E.USE_FUSED_MLP = False          # no weight images in the descriptor: concat pass, GEMM, breakup tail kernel
+    try:
+        out2 = u(xb.to(DEV)).cpu()
+    finally:
+        E.USE_FUSED_MLP = saved
+    rel_close(out2, ref)
+    # the one-pass kernel normalises the fp32 accumulators, the other path the fp32 GEMM output: same roundings up to
+    # summation order, amplified by the two LayerNorms
+    d = (out - out2).abs()
+    scale = float(ref.abs().max())
+    assert float(d.max()) <= 1e-2 * scale and float(d.mean()) <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
+
+
 # C=768 with UN-clamped windows (the last stage of the full-size nets: res 12 / w 6 and res 16 / w 8, 4 windows per
 # graph), which no reduced golden geometry reaches; shifted variants exercise the mask path of that kernel route.
 BIG_BLOCK_CASES = {
