@@ -182,6 +182,31 @@ def test_patch_breakup_one_pass_kernel_matches_oracle_and_gemm_path(name):
     assert float(d.max()) <= 1e-2 * scale and float(d.mean()) <= 2e-4 * scale, (float(d.max()), float(d.mean()), scale)
 
 
+def test_patch_breakup_in_place_call_takes_the_safe_path():
+    """swg_patch_expand_fwd with x_out starting at x (the way a caller with one token tensor would use it): the
+    one-pass kernel cannot run in place (a workgroup's output rows are other workgroups' input rows), so the library
+    must fall back to the concat + GEMM + tail route, which reads x completely before anything is written."""
+    import ctypes as C
+    import swingnn_amd as S
+    from swingnn_amd import _lib as L, engine as E
+    dim, res, B, seed = 384, 48, 8, 79
+    sd = H.breakup_state(dim, seed)
+    u = load(S.PatchBreakup((res,) * 2, dim), strip(sd, "u."))
+    xb = filler.uniform("xb", (B, res ** 2, dim), seed)
+    ref = O.patch_breakup(xb, sd, "u", res)
+    T = B * res * res
+    x, skip = [t.contiguous().to(DEV) for t in xb.chunk(2, dim=-1)]
+    buf = torch.empty(T * dim, dtype=torch.float32, device=DEV)     # out [4T, dim/4]; x occupies its first half
+    buf[:T * dim // 2].copy_(x.reshape(-1))
+    keep = E.Keep()
+    desc = E.breakup_desc(keep, u)
+    assert desc.img_pre and desc.img_post
+    ws = torch.empty(64 * x.numel() * 4 + (1 << 20), dtype=torch.uint8, device=DEV)
+    L.check(L.lib.swg_patch_expand_fwd(C.byref(desc), B, buf.data_ptr(), skip.data_ptr(), buf.data_ptr(), ws.data_ptr(),
+                                       ws.numel(), E.stream_ptr()), "swg_patch_expand_fwd")
+    rel_close(buf.reshape(B, 4 * res * res, dim // 4), ref)
+
+
 # C=768 with UN-clamped windows (the last stage of the full-size nets: res 12 / w 6 and res 16 / w 8, 4 windows per
 # graph), which no reduced golden geometry reaches; shifted variants exercise the mask path of that kernel route.
 BIG_BLOCK_CASES = {
