@@ -109,6 +109,39 @@ def test_precond_grid384_batched_pass_matches_oracle(monkeypatch):
     assert filt >= 0.999 and raw >= 0.999, (raw, filt)
 
 
+def test_precond_dd512_batched_pass_matches_oracle(monkeypatch):
+    """The DD geometry (N = 512, 8x8 windows) at B = 4: the smallest batch at which the one-pass PatchMerging
+    (C = 96: 4 x 64^2 = 16384 merged tokens) and PatchBreakup (Cin = 384: 4 x 64^2 input tokens) kernels run inside the
+    network pass; every graph is held to the oracle."""
+    import swingnn_amd as S
+    c = FULL_CASES["dd512"]
+    cfg = dict(img_size=c["img"], patch_size=c["p"], in_chans=1, embed_dim=c["dim"], depths=c["depths"],
+               num_heads=HEADS, window_size=c["window"], self_condition=True)
+    net = S.SwinGNN(img_size=c["img"], patch_size=c["p"], in_chans=1, embed_dim=c["dim"], depths=c["depths"],
+                    num_heads=HEADS, window_size=c["window"], mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
+                    drop_path_rate=0.0, self_condition=True)
+    pre = S.Precond("edm", net, True)
+    sd = filler.fill_state_dict(pre.state_dict(), c["seed"], "init")
+    pre.load_state_dict(sd)
+    pre = pre.to(DEV).eval()
+    N, B = c["img"], 4
+    n_nodes = torch.tensor([500, 233, 401, 512])
+    flags = (torch.arange(N)[None, :] < n_nodes[:, None]).to(torch.float32)
+    sig = torch.tensor([0.1, 1.5, 4.0, 20.0], dtype=torch.float32)
+    x = torch.cat([filler.sym_adj("x", 1, N, flags[i:i + 1], c["seed"] + 200 + i,
+                                  scale=float(np.sqrt(float(sig[i]) ** 2 + 0.25))) for i in range(B)])
+    monkeypatch.setattr(np.random, "rand", lambda: 0.25)   # self-conditioning branch: two passes
+    out = pre(x.to(DEV), flags.to(DEV), sig.to(DEV)).cpu()
+    monkeypatch.undo()
+    pre.assert_symmetric()
+    ref = O.precond_forward(sd, cfg, x, flags, sig, True)
+    err = float((out - ref).abs().max())
+    raw, filt = agreement(out, ref, flags)
+    print(f"dd512 B={B}: max err {err:.3g}, agreement raw {raw:.5f} filtered {filt:.5f}")
+    assert err <= 1e-2, err
+    assert filt >= 0.999 and raw >= 0.999, (raw, filt)
+
+
 # PatchMerging at token counts where the one-pass kernel (csrc/merge_fused.hip) runs: >= 16384 merged tokens, C = 96 /
 # 192; the reduced golden geometries stay on the LayerNorm pass + GEMM.  Ragged cases: merged token counts that are
 # not a multiple of the 128-token workgroup, odd merged side.
