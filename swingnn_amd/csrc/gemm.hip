@@ -36,14 +36,20 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
   return start + slot;
 }
 
-template <int BK>
+// BMT: token rows per block tile.  128 (4 x 4 MFMA tiles per wave) is the default; 64 (2 x 4 per wave) doubles the
+// workgroup count for shapes that would otherwise put one or two workgroups on a CU: with so few waves the
+// register-staged pipeline exposes a memory latency per k-step (C = 768 fc2 at M = 8064: 378 workgroups, 70 us for
+// 14 us of MFMA work).
+template <int BK, int BMT = 128>
 __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int lda, const bf16* __restrict__ W, int ldw,
                                                  int M, int N, int Kp, GemmEpi e, int tiles_n, int kslice,
                                                  size_t out_slice) {
   constexpr int CH = Swz<BK>::CH;
-  constexpr int LD_PER_THR = (BM * CH) / 256;  // 16-byte chunks per thread per operand tile
+  constexpr int LDX = (BMT * CH) / 256;  // 16-byte chunks per thread of the activation tile
+  constexpr int LDW = (BN * CH) / 256;   // ... of the weight tile
+  constexpr int MT = BMT / 32;           // 16-token MFMA tiles per wave
   constexpr int KSTEPS = BK / 32;
-  __shared__ __attribute__((aligned(16))) bf16 sX[2][BM * BK];
+  __shared__ __attribute__((aligned(16))) bf16 sX[2][BMT * BK];
   __shared__ __attribute__((aligned(16))) bf16 sW[2][BN * BK];
 
   const int nwg = gridDim.x;
@@ -56,7 +62,7 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
   }
   const int tile = xcd_remap(blockIdx.x, nwg);
   const int tm = tile / tiles_n, tn = tile - tm * tiles_n;  // n fastest: neighbours share the X panel
-  const int m0 = tm * BM, n0 = tn * BN;
+  const int m0 = tm * BMT, n0 = tn * BN;
 
   const int tid = threadIdx.x;
   const int lane = tid & 63, wave = tid >> 6;
@@ -64,45 +70,47 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
   const int l15 = lane & 15, lg = lane >> 4;
 
   // global -> register staging (plain unrolled code: arrays captured by lambdas end up in scratch memory)
-  bf16x8 rx[LD_PER_THR], rw[LD_PER_THR];
-  const bf16* gx[LD_PER_THR];
-  const bf16* gw[LD_PER_THR];
-  int soff[LD_PER_THR];
+  bf16x8 rx[LDX], rw[LDW];
+  const bf16* gx[LDX];
+  const bf16* gw[LDW];
+  int soff[LDW];  // the same (row, chunk) -> LDS offset map serves both tiles (LDX <= LDW)
 #pragma unroll
-  for (int i = 0; i < LD_PER_THR; ++i) {
+  for (int i = 0; i < LDW; ++i) {
     const int id = tid + i * 256;
     const int row = id / CH, ch = id - row * CH;
-    gx[i] = A + (size_t)min(m0 + row, M - 1) * lda + ch * 8;
+    if (i < LDX) gx[i < LDX ? i : 0] = A + (size_t)min(m0 + row, M - 1) * lda + ch * 8;
     gw[i] = W + (size_t)min(n0 + row, N - 1) * ldw + ch * 8;
     soff[i] = row * BK + Swz<BK>::chunk(row, ch) * 8;
   }
-#define G_LOAD(KT)                                                             \
-  _Pragma("unroll") for (int i = 0; i < LD_PER_THR; ++i) {                     \
-    rx[i] = *reinterpret_cast<const bf16x8*>(gx[i] + (KT) * BK);                \
-    rw[i] = *reinterpret_cast<const bf16x8*>(gw[i] + (KT) * BK);                \
+#define G_LOAD(KT)                                                                            \
+  _Pragma("unroll") for (int i = 0; i < LDW; ++i) {                                           \
+    if (i < LDX) rx[i < LDX ? i : 0] = *reinterpret_cast<const bf16x8*>(gx[i < LDX ? i : 0] + (KT) * BK); \
+    rw[i] = *reinterpret_cast<const bf16x8*>(gw[i] + (KT) * BK);                               \
   }
-#define S_STORE(BUF)                                                           \
-  _Pragma("unroll") for (int i = 0; i < LD_PER_THR; ++i) {                     \
-    *reinterpret_cast<bf16x8*>(&sX[BUF][soff[i]]) = rx[i];                      \
-    *reinterpret_cast<bf16x8*>(&sW[BUF][soff[i]]) = rw[i];                      \
+#define S_STORE(BUF)                                                                          \
+  _Pragma("unroll") for (int i = 0; i < LDW; ++i) {                                           \
+    if (i < LDX) *reinterpret_cast<bf16x8*>(&sX[BUF][soff[i]]) = rx[i < LDX ? i : 0];          \
+    *reinterpret_cast<bf16x8*>(&sW[BUF][soff[i]]) = rw[i];                                     \
   }
 
-  f32x4 acc[4][4];  // [nt][mt]
+  f32x4 acc[4][MT];  // [nt][mt]
 #pragma unroll
   for (int i = 0; i < 4; ++i)
 #pragma unroll
-    for (int j = 0; j < 4; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
+    for (int j = 0; j < MT; ++j) acc[i][j] = (f32x4){0.f, 0.f, 0.f, 0.f};
 
   // fragment read offsets (elements) of this lane, per 32-deep k-step
-  int fwo[4][KSTEPS], fxo[4][KSTEPS];
+  int fwo[4][KSTEPS], fxo[MT][KSTEPS];
 #pragma unroll
   for (int t = 0; t < 4; ++t)
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
       const int rw_ = wn * 64 + t * 16 + l15;
-      const int rx_ = wm * 64 + t * 16 + l15;
       fwo[t][ks] = rw_ * BK + Swz<BK>::chunk(rw_, ks * 4 + lg) * 8;
-      fxo[t][ks] = rx_ * BK + Swz<BK>::chunk(rx_, ks * 4 + lg) * 8;
+      if (t < MT) {
+        const int rx_ = wm * (16 * MT) + t * 16 + l15;
+        fxo[t < MT ? t : 0][ks] = rx_ * BK + Swz<BK>::chunk(rx_, ks * 4 + lg) * 8;
+      }
     }
 
   const int nk = Kp / BK;
@@ -114,16 +122,16 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
     if (kt + 1 < nk) { G_LOAD(kt + 1); }
 #pragma unroll
     for (int ks = 0; ks < KSTEPS; ++ks) {
-      bf16x8 fw[4], fx[4];
+      bf16x8 fw[4], fx[MT];
 #pragma unroll
       for (int t = 0; t < 4; ++t) {
         fw[t] = *reinterpret_cast<const bf16x8*>(&sW[buf][fwo[t][ks]]);
-        fx[t] = *reinterpret_cast<const bf16x8*>(&sX[buf][fxo[t][ks]]);
+        if (t < MT) fx[t < MT ? t : 0] = *reinterpret_cast<const bf16x8*>(&sX[buf][fxo[t < MT ? t : 0][ks]]);
       }
 #pragma unroll
       for (int nt = 0; nt < 4; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 4; ++mt)
+        for (int mt = 0; mt < MT; ++mt)
           acc[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(fw[nt], fx[mt], acc[nt][mt], 0, 0, 0);
     }
     if (kt + 1 < nk) { S_STORE(buf ^ 1); }
@@ -134,8 +142,8 @@ __global__ __launch_bounds__(256) void k_gemm_nt(const bf16* __restrict__ A, int
 
   // epilogue: lane owns token m = ... + l15 and features n = ... + 4*lg + {0..3}
 #pragma unroll
-  for (int mt = 0; mt < 4; ++mt) {
-    const int m = m0 + wm * 64 + mt * 16 + l15;
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = m0 + wm * (16 * MT) + mt * 16 + l15;
     if (m >= M) continue;
     const float* crow = e.cond ? e.cond + (size_t)(m / e.cond_L) * e.cond_stride + e.cond_off : nullptr;
 #pragma unroll
@@ -584,6 +592,19 @@ int launch_gemm(const bf16* A, int lda, const bf16* W, int M, int N, int Kp, con
                   2.0 * M * Kp + 2.0 * N * (double)Kp + osz * M * (double)N + (ee.residual ? 4.0 * M * (double)N : 0.0), s);
   if (form == 3) {
     hipLaunchKernelGGL((k_gemm_nt_big<8, 3>), dim3(big_wg), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n);
+    SWG_LAUNCH_CHECK();
+    return 0;
+  }
+  // few workgroups (at most two per CU): 64-row tiles double their number.  Measured at B = 56 (scripts/bench_gemm.py,
+  // SWG_GEMM_BM64 = 0 / 1): C = 768 proj 30.9 -> 24.5 us, fc2 70.9 -> 62.0 us, the 384 -> 768 merge 38.1 -> 33.5 us;
+  // at 756 workgroups (M = 32256, N = 384) the 128-row tile is still the better one
+  static const int small_m = [] { const char* v = getenv("SWG_GEMM_BM64"); return v ? atoi(v) : 1; }();
+  if (small_m && nwg <= 512 && M >= 128) {
+    const int nwg64 = cdiv(M, 64) * tiles_n;
+    if (Kp % 64 == 0)
+      hipLaunchKernelGGL((k_gemm_nt<64, 64>), dim3(nwg64), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n, 0, (size_t)0);
+    else
+      hipLaunchKernelGGL((k_gemm_nt<32, 64>), dim3(nwg64), dim3(256), 0, s, A, lda, W, Kp, M, N, Kp, ee, tiles_n, 0, (size_t)0);
     SWG_LAUNCH_CHECK();
     return 0;
   }
