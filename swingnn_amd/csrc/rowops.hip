@@ -875,6 +875,63 @@ __global__ __launch_bounds__(256) void k_heun_correct(int N, size_t total, const
   xn[i] = o;
 }
 
+// float4 forms of the two updates for N % 4 == 0 (four entries of one row per thread: one row / column decode and four
+// 16-byte accesses instead of four of each; the per-entry arithmetic is the scalar kernels' own, results bit-identical)
+__global__ __launch_bounds__(256) void k_heun_euler4(int N, size_t total4, const float* __restrict__ xh,
+                                                     const float* __restrict__ den, const float* __restrict__ flags,
+                                                     float inv_t, float h, int mask_out, float* __restrict__ d_cur,
+                                                     float* __restrict__ xp) {
+  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 >= total4) return;
+  const size_t i = i4 * 4, nn = (size_t)N * N;
+  const int bi = (int)(i / nn);
+  const int rem = (int)(i - (size_t)bi * nn);
+  const int r = rem / N, c = rem - r * N;
+  const bool mr = flags[(size_t)bi * N + r] != 0.f;
+  const float4 fc = *reinterpret_cast<const float4*>(flags + (size_t)bi * N + c);
+  const float4 xv = *reinterpret_cast<const float4*>(xh + i);
+  const float4 dv = *reinterpret_cast<const float4*>(den + i);
+  const float x4[4] = {xv.x, xv.y, xv.z, xv.w}, d4[4] = {dv.x, dv.y, dv.z, dv.w}, f4[4] = {fc.x, fc.y, fc.z, fc.w};
+  float dd[4], oo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const bool m = mr && f4[e] != 0.f;
+    dd[e] = m ? (inv_t * x4[e] - inv_t * d4[e]) : 0.f;
+    const float o = x4[e] + h * dd[e];
+    oo[e] = (mask_out && !m) ? 0.f : o;
+  }
+  if (d_cur) *reinterpret_cast<float4*>(d_cur + i) = make_float4(dd[0], dd[1], dd[2], dd[3]);
+  *reinterpret_cast<float4*>(xp + i) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+}
+
+__global__ __launch_bounds__(256) void k_heun_correct4(int N, size_t total4, const float* __restrict__ xh,
+                                                       const float* __restrict__ xp, const float* __restrict__ d_cur,
+                                                       const float* __restrict__ den2, const float* __restrict__ flags,
+                                                       float inv_tp, float h, float* __restrict__ xn) {
+  const size_t i4 = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i4 >= total4) return;
+  const size_t i = i4 * 4, nn = (size_t)N * N;
+  const int bi = (int)(i / nn);
+  const int rem = (int)(i - (size_t)bi * nn);
+  const int r = rem / N, c = rem - r * N;
+  const bool mr = flags[(size_t)bi * N + r] != 0.f;
+  const float4 fc = *reinterpret_cast<const float4*>(flags + (size_t)bi * N + c);
+  const float4 a = *reinterpret_cast<const float4*>(xh + i), b = *reinterpret_cast<const float4*>(xp + i);
+  const float4 dc = *reinterpret_cast<const float4*>(d_cur + i), d2 = *reinterpret_cast<const float4*>(den2 + i);
+  const float xh4[4] = {a.x, a.y, a.z, a.w}, xp4[4] = {b.x, b.y, b.z, b.w}, dc4[4] = {dc.x, dc.y, dc.z, dc.w},
+              d24[4] = {d2.x, d2.y, d2.z, d2.w}, f4[4] = {fc.x, fc.y, fc.z, fc.w};
+  float oo[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    oo[e] = 0.f;
+    if (mr && f4[e] != 0.f) {
+      const float dp = inv_tp * xp4[e] - inv_tp * d24[e];
+      oo[e] = xh4[e] + h * (0.5f * dc4[e] + 0.5f * dp);
+    }
+  }
+  *reinterpret_cast<float4*>(xn + i) = make_float4(oo[0], oo[1], oo[2], oo[3]);
+}
+
 __global__ __launch_bounds__(256) void k_mask_adjs(int N, size_t total, float* __restrict__ a,
                                                    const float* __restrict__ flags) {
   const size_t i = (size_t)blockIdx.x * blockDim.x + threadIdx.x;
@@ -1016,8 +1073,12 @@ int swg_heun_euler(int32_t B, int32_t N, const float* x_hat, const float* denois
   if (B <= 0 || N <= 0 || t_hat == 0.f) return SWG_E_SHAPE;
   const size_t total = (size_t)B * N * N;
   SwgProfScope ps(KID_HEUN, 0.0, 16.0 * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_heun_euler, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, total,
-                     x_hat, denoised, node_flags, 1.0f / t_hat, h, mask_out, d_cur, x_prime);
+  if (N % 4 == 0)
+    hipLaunchKernelGGL(k_heun_euler4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
+                       total / 4, x_hat, denoised, node_flags, 1.0f / t_hat, h, mask_out, d_cur, x_prime);
+  else
+    hipLaunchKernelGGL(k_heun_euler, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N, total,
+                       x_hat, denoised, node_flags, 1.0f / t_hat, h, mask_out, d_cur, x_prime);
   SWG_LAUNCH_CHECK();
   return 0;
 }
@@ -1029,8 +1090,12 @@ int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_pr
   if (B <= 0 || N <= 0 || t_prime == 0.f) return SWG_E_SHAPE;
   const size_t total = (size_t)B * N * N;
   SwgProfScope ps(KID_HEUN, 0.0, 20.0 * total, (hipStream_t)stream);
-  hipLaunchKernelGGL(k_heun_correct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
-                     total, x_hat, x_prime, d_cur, denoised2, node_flags, 1.0f / t_prime, h, x_next);
+  if (N % 4 == 0)
+    hipLaunchKernelGGL(k_heun_correct4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
+                       total / 4, x_hat, x_prime, d_cur, denoised2, node_flags, 1.0f / t_prime, h, x_next);
+  else
+    hipLaunchKernelGGL(k_heun_correct, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
+                       total, x_hat, x_prime, d_cur, denoised2, node_flags, 1.0f / t_prime, h, x_next);
   SWG_LAUNCH_CHECK();
   return 0;
 }
