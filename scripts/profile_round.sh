@@ -18,6 +18,6 @@ cd $R
 bash scripts/pmc_traffic.sh $B > gpurun_out/${TAG}_pmc_traffic.log 2>&1
 cp gpurun_out/pmc_traffic.json gpurun_out/${TAG}_pmc_traffic.json
 echo "traffic done"
-bash scripts/pmc_forward.sh $B k_wattn k_mlp k_gemm k_row > gpurun_out/${TAG}_pmc_forward.log 2>&1
+bash scripts/pmc_forward.sh $B k_wattn k_mlp k_gemm k_row k_merge k_expand k_patch k_breakup k_final k_sym > gpurun_out/${TAG}_pmc_forward.log 2>&1
 cat gpurun_out/pmc_fwd_summary_1.txt gpurun_out/pmc_fwd_summary_2.txt > gpurun_out/${TAG}_forward_sq_counters_b${B}.txt
 echo "sq done"
