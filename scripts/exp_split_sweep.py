@@ -10,7 +10,7 @@ dev = torch.device('cuda:0')
 model = bench.build_model(cfg, dev)
 np.random.rand = lambda: 0.9
 combos = {'grid': [(112, 1), (112, 2), (168, 2), (168, 3), (224, 2), (224, 4), (280, 5), (84, 3), (56, 2), (56, 1)],
-          'dd': [(56, 1), (56, 2), (112, 2), (112, 1), (112, 4), (84, 3), (28, 1)]}[cfgname]
+          'dd': [(56, 1), (56, 2), (64, 1), (64, 2), (128, 2), (112, 2), (32, 1)]}[cfgname]
 for B, parts in combos:
     E.SPLIT_STREAMS = parts
     E.SPLIT_MIN_WORK = 0

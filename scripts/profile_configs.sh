@@ -5,7 +5,7 @@ set -e
 TAG=${1:-r02}
 R=$GRAFT_REPO_ROOT
 cd $R
-timeout -k 10 400 python3 bench.py --config dd --batch 56 --no-cpu-baseline > gpurun_out/${TAG}_bench_dd96_b56.json 2> gpurun_out/${TAG}_bench_dd.err
+timeout -k 10 800 python3 bench.py --config dd --batch 112 --no-cpu-baseline > gpurun_out/${TAG}_bench_dd96_b112.json 2> gpurun_out/${TAG}_bench_dd.err
 echo "dd done"
 timeout -k 10 300 python3 bench.py --config community_small --batch 2048 --no-cpu-baseline > gpurun_out/${TAG}_bench_community_small96_b2048.json 2> gpurun_out/${TAG}_bench_com.err
 echo "com done"
