@@ -65,11 +65,31 @@ __device__ __forceinline__ float gelu_f(float x) {
 }
 
 // sum over a group of LANES consecutive lanes (LANES power of two <= 64)
+// Sum over an aligned group of LANES lanes; every lane ends with the total.  Groups of 16 / 32 / 64 lanes use the gfx950
+// row-swap instructions and DPP row rotations (VALU only) in the SAME combination order as the xor butterfly below
+// (32, 16 across rows, then 8, 4, 2, 1 inside a row), so the results are bit-identical to it; a ds_bpermute per step
+// costs an LDS latency each, ten of them per LayerNorm row.
 template <int LANES>
 __device__ __forceinline__ float group_sum(float v) {
+  if constexpr (LANES >= 16) {
+    if constexpr (LANES == 64) {
+      auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+    }
+    if constexpr (LANES >= 32) {
+      auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+      v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+    }
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x128, 0xf, 0xf, false));  // row_ror:8
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x124, 0xf, 0xf, false));  // row_ror:4
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x122, 0xf, 0xf, false));  // row_ror:2
+    v += __uint_as_float(__builtin_amdgcn_update_dpp(0u, __float_as_uint(v), 0x121, 0xf, 0xf, false));  // row_ror:1
+    return v;
+  } else {
 #pragma unroll
-  for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
-  return v;
+    for (int o = LANES / 2; o > 0; o >>= 1) v += __shfl_xor(v, o, 64);
+    return v;
+  }
 }
 
 // Reductions over the four 16-lane rows of a wavefront (lanes l, l^16, l^32, l^48) with the gfx950 row-swap
