@@ -144,8 +144,7 @@ __global__ __launch_bounds__(256) void k_wattn_core(WattnArgs a) {
         p[kt][qt][r] = s;
         mx = fmaxf(mx, s);
       }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    mx = rows_max(mx);  // over lanes l, l^16, l^32, l^48 (row swaps in the VALU instead of two ds_bpermute)
     float sum = 0.f;
 #pragma unroll
     for (int kt = 0; kt < NT; ++kt)
@@ -155,8 +154,12 @@ __global__ __launch_bounds__(256) void k_wattn_core(WattnArgs a) {
         p[kt][qt][r] = e;
         sum += e;
       }
-    sum += __shfl_xor(sum, 16, 64);
-    sum += __shfl_xor(sum, 32, 64);
+    {  // same combination order as the xor-16, xor-32 butterfly it replaces
+      auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+      sum = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+      auto c = __builtin_amdgcn_permlane32_swap(__float_as_uint(sum), __float_as_uint(sum), false, false);
+      sum = __uint_as_float(c[0]) + __uint_as_float(c[1]);
+    }
     inv_sum[qt] = fast_rcp(sum);
   }
 
