@@ -190,6 +190,8 @@ def main():
     ap.add_argument("--num-steps", type=int, default=256, help="Heun steps (256 = the shipped configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-pass-reuse", action="store_true", help="skip the extra (non-headline) run with reuse_passes")
+    ap.add_argument("--graphs", type=int, default=0, choices=(0, 1),
+                    help="1: EDMSampler.use_graphs (every network pass is one HIP-graph launch; same kernels, same bits)")
     args = ap.parse_args()
 
     rank, local_rank, world = rank_env()
@@ -207,6 +209,7 @@ def main():
     model = build_model(cfg, dev)
     sampler = S.EDMSampler(num_steps=args.num_steps, clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
                            clip_samples_scope="x_0", self_condition=True, dev=dev)
+    sampler.use_graphs = bool(args.graphs)
     seed = 1234 + rank  # utils/arg_parser.py:254-255
     torch.manual_seed(seed)
     np.random.seed(seed)
@@ -270,6 +273,7 @@ def main():
                                    f"dim-{cfg['embed_dim']}, depths {cfg['depths']}, window {cfg['window_size']}, "
                                    f"{args.num_steps} steps, self_cond, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "launch": "HIP-graph replay per network pass" if args.graphs else "eager kernel launches",
                        "parallelism": f"independent replicas x{world} (batch-sharded, no collective)"},
             "roofline": roof,
             "window_attn": wattn,

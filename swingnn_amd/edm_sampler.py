@@ -86,6 +86,13 @@ class EDMSampler(GeneralSampler):
         # samples are bit-identical (tests/test_gpu_parity.py::test_pass_reuse_is_bit_identical).  Off by default so that
         # the default run executes every network pass the reference executes.
         self.reuse_passes = False
+        # Opt-in (not a reference option): run every network pass as ONE HIP-graph launch (engine.graphed_pass) instead
+        # of ~60 kernel launches, so a Heun step costs the host thread ~10 enqueues instead of ~130-190 (ranks sharing a
+        # contended host; small launch-bound problems).  The state buffers are then kept on the sampler between
+        # sample() calls so the recorded addresses stay valid; same kernels in the same order, bit-identical samples
+        # (tests/test_gpu_parity.py::test_graph_replayed_sampler_is_bit_identical).
+        self.use_graphs = False
+        self._graph_bufs = {}
 
     # overridable so that parity tests can inject pre-drawn noise
     def _randn_like(self, x):
@@ -133,51 +140,76 @@ class EDMSampler(GeneralSampler):
         lib, sp = L.lib, E.stream_ptr
 
         x_next = (E._as_f32(init_adjs) * float(self.sigma_steps[0].to(torch.float32))).contiguous()
-        x_hat, x_prime, d_cur = torch.empty_like(x_next), torch.empty_like(x_next), torch.empty_like(x_next)
+        graphs = bool(self.use_graphs and masked_model and gt is None and hasattr(inner, "use_graphs"))
+        sig_slot = None
+        if graphs:
+            # recorded passes read x_hat / flags / sigma at fixed addresses: these live on the sampler across calls
+            key = (str(dev), B, N)
+            bufs = self._graph_bufs.get(key)
+            if bufs is None:
+                self._graph_bufs.clear()
+                bufs = self._graph_bufs[key] = dict(x_hat=torch.empty_like(x_next), flags=torch.empty_like(flags),
+                                                    sig=torch.empty(1, dtype=torch.float32, device=dev))
+            x_hat, sig_slot = bufs["x_hat"], bufs["sig"]
+            flags = bufs["flags"].copy_(flags)
+            x_prime, d_cur = torch.empty_like(x_next), torch.empty_like(x_next)
+        else:
+            x_hat, x_prime, d_cur = torch.empty_like(x_next), torch.empty_like(x_next), torch.empty_like(x_next)
         # nothing is allocated or copied host -> device inside the loop: the state ping-pongs between two buffers and
         # every step's sigma_hat sits in one device vector (the model sees a [1] view expanded to [B], edm.py:180)
         state = [x_next, torch.empty_like(x_next)]
         sig_all = torch.tensor([c[0] for c in consts], dtype=torch.float32, device=dev)
         x_self_cond = None
         reuse = bool(self.reuse_passes and masked_model and gt is None and hasattr(inner, "_step_memo"))
-        for i, (t_hat, coef, h, t_prime) in enumerate(consts):
-            x_cur = x_next
-            if reuse:
-                inner._step_memo = {}
-            raw = self._randn_like(x_cur)
-            L.check(lib.swg_heun_churn(B, N, x_cur.data_ptr(), raw.data_ptr(), flags.data_ptr(), coef,
-                                       x_hat.data_ptr(), sp()), "swg_heun_churn")
-            sig = sig_all[i:i + 1].expand(B)
-            if gt is None:
-                with torch.no_grad():
-                    den = model(x_hat, flags, sig, x_self_cond)
-                if not masked_model:
-                    den = E._as_f32(den)
-                    L.check(lib.swg_mask_adjs(B, N, den.data_ptr(), flags.data_ptr(), sp()), "swg_mask_adjs")
-            else:
-                den = gt
-            last = self.solver == 'euler' or i == self.num_steps - 1
-            x_next = state[(i + 1) & 1]
-            L.check(lib.swg_heun_euler(B, N, x_hat.data_ptr(), den.data_ptr(), flags.data_ptr(), t_hat, h, int(last),
-                                       d_cur.data_ptr(), (x_next if last else x_prime).data_ptr(), sp()),
-                    "swg_heun_euler")
-            if not last:
+        was_graphs = getattr(inner, "use_graphs", False)
+        if graphs:
+            inner.use_graphs = True
+        try:
+            for i, (t_hat, coef, h, t_prime) in enumerate(consts):
+                x_cur = x_next
+                if reuse:
+                    inner._step_memo = {}
+                raw = self._randn_like(x_cur)
+                L.check(lib.swg_heun_churn(B, N, x_cur.data_ptr(), raw.data_ptr(), flags.data_ptr(), coef,
+                                           x_hat.data_ptr(), sp()), "swg_heun_churn")
+                if graphs:
+                    sig_slot.copy_(sig_all[i:i + 1])   # device -> device, 4 bytes: the recorded passes read this slot
+                    sig = sig_slot.expand(B)
+                else:
+                    sig = sig_all[i:i + 1].expand(B)
                 if gt is None:
-                    x_self_cond = den if self.self_condition else None
                     with torch.no_grad():
-                        den = model(x_hat, flags, sig, x_self_cond)  # (x_hat, t_hat) again: edm.py:201-205
-                L.check(lib.swg_heun_correct(B, N, x_hat.data_ptr(), x_prime.data_ptr(), d_cur.data_ptr(),
-                                             den.data_ptr(), flags.data_ptr(), t_prime, h, x_next.data_ptr(), sp()),
-                        "swg_heun_correct")
-            x_self_cond = den if self.self_condition else None
-            if reuse:
-                inner._step_memo = None
-            L.check(lib.swg_sym_check(B, N, x_next.data_ptr(), sym_acc.data_ptr(), sp()), "swg_sym_check")
-            if flag_interim_adjs and i in snaps:
-                adjs_ls.append(x_next.cpu())
-            if debug:
-                logging.debug("EDM MCMC: step {:5d} | avg. #edges@0.0 of x_t: {:08d} |".format(
-                    i, int(EDMSampler.get_num_edges(x_next, flags, 0.0).mean().item())))
+                        den = model(x_hat, flags, sig, x_self_cond)
+                    if not masked_model:
+                        den = E._as_f32(den)
+                        L.check(lib.swg_mask_adjs(B, N, den.data_ptr(), flags.data_ptr(), sp()), "swg_mask_adjs")
+                else:
+                    den = gt
+                last = self.solver == 'euler' or i == self.num_steps - 1
+                x_next = state[(i + 1) & 1]
+                L.check(lib.swg_heun_euler(B, N, x_hat.data_ptr(), den.data_ptr(), flags.data_ptr(), t_hat, h, int(last),
+                                           d_cur.data_ptr(), (x_next if last else x_prime).data_ptr(), sp()),
+                        "swg_heun_euler")
+                if not last:
+                    if gt is None:
+                        x_self_cond = den if self.self_condition else None
+                        with torch.no_grad():
+                            den = model(x_hat, flags, sig, x_self_cond)  # (x_hat, t_hat) again: edm.py:201-205
+                    L.check(lib.swg_heun_correct(B, N, x_hat.data_ptr(), x_prime.data_ptr(), d_cur.data_ptr(),
+                                                 den.data_ptr(), flags.data_ptr(), t_prime, h, x_next.data_ptr(), sp()),
+                            "swg_heun_correct")
+                x_self_cond = den if self.self_condition else None
+                if reuse:
+                    inner._step_memo = None
+                L.check(lib.swg_sym_check(B, N, x_next.data_ptr(), sym_acc.data_ptr(), sp()), "swg_sym_check")
+                if flag_interim_adjs and i in snaps:
+                    adjs_ls.append(x_next.cpu())
+                if debug:
+                    logging.debug("EDM MCMC: step {:5d} | avg. #edges@0.0 of x_t: {:08d} |".format(
+                        i, int(EDMSampler.get_num_edges(x_next, flags, 0.0).mean().item())))
+        finally:
+            if graphs:
+                inner.use_graphs = was_graphs
         adjs = x_next.cpu()  # syncs the stream
         assert float(sym_acc.item()) < 1e-2, "sampler state lost symmetry"
         if masked_model:

@@ -610,7 +610,8 @@ def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
     if out is None:
         out = torch.empty_like(x)
     parts = SPLIT_STREAMS
-    if (parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK or torch.cuda.is_current_stream_capturing()):
+    if (parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK or
+            (torch.cuda.is_current_stream_capturing() and not _CAPTURE_SPLIT)):
         _launch_pass(cache, B, mode, x, flags, labels, labels_uniform, sc, out, sym_err)
         return out
     h = B // parts
@@ -634,6 +635,72 @@ def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
         join.record(side)
         cur.wait_event(join)   # later work on the caller's stream (and frees of x / out) is ordered after the parts
     return out
+
+
+_CAPTURE_SPLIT = False       # set while graphed_pass records: the part-batch fork / join is captured too
+GRAPH_SLOTS = 8              # captured passes kept per NetCache (each owns one [B,N,N] output buffer)
+GRAPH_REPLAYS = 0            # passes executed as graph replays (reported by bench.py)
+
+
+def graphed_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_uniform: bool, self_cond, sym_err=None):
+    """network_pass as ONE HIP-graph launch: the ~60 kernel launches of a pass (and the two part-batch branches with
+    their fork / join) are recorded once per distinct set of buffer ADDRESSES and replayed afterwards, so the host
+    thread enqueues one node instead of sixty (ranks sharing a contended host, small launch-bound problems).
+
+    The recorded kernels read x / node_flags / labels / self_cond at the addresses they had when the graph was recorded
+    and write into an output buffer the graph owns: callers keep their inputs in place and refill them between calls
+    (EDMSampler(use_graphs=True) does), and the returned tensor is overwritten by the next replay of the same graph.
+    Same kernels, same launch geometry, same order within a part-batch as the eager pass: results are bit-identical
+    (tests/test_gpu_parity.py::test_graph_replayed_sampler_is_bit_identical).  Graphs live on the NetCache, i.e. they
+    are dropped together with the weight images when the parameters are replaced."""
+    global PASS_COUNT, GRAPH_REPLAYS, _CAPTURE_SPLIT
+    if x.dtype != torch.float32 or not x.is_contiguous() or _PROFILING or torch.cuda.is_current_stream_capturing():
+        return network_pass(cache, mode, x, node_flags, labels, labels_uniform, self_cond, sym_err=sym_err)
+    flags, labels = _as_f32(node_flags), _as_f32(labels)
+    sc = None if self_cond is None else _as_f32(self_cond)
+    key = (cache.generation, mode, tuple(x.shape), x.data_ptr(), flags.data_ptr(), labels.data_ptr(),
+           bool(labels_uniform), _ptr(sc) or 0, _ptr(sym_err) or 0, torch.cuda.current_stream().cuda_stream)
+    graphs = cache.__dict__.setdefault("_graphs", {})
+    if graphs and next(iter(graphs))[0] != cache.generation:   # parameters refreshed: ro_b is baked into the nodes
+        graphs.clear()
+    ent = graphs.get(key)
+    if ent is None:
+        out = torch.empty_like(x)
+        # eager run first: sizes the per-stream workspaces and sets the kernels' LDS opt-ins outside the recording
+        network_pass(cache, mode, x, flags, labels, labels_uniform, sc, out=out, sym_err=None)
+        cs = _capture_stream(x.device)
+        if launch_batch(x.shape[0], x.shape[-1]) == x.shape[0]:
+            with torch.cuda.stream(cs):   # an unsplit pass records on `cs`: its workspace comes from the ordinary pool
+                workspace(x.device, cache.ws_bytes(x.shape[0]))
+        graph = torch.cuda.CUDAGraph()
+        _CAPTURE_SPLIT = True
+        try:
+            with torch.cuda.graph(graph, stream=cs):
+                network_pass(cache, mode, x, flags, labels, labels_uniform, sc, out=out, sym_err=sym_err)
+        finally:
+            _CAPTURE_SPLIT = False
+        PASS_COUNT -= 1          # the recording launched nothing
+        while len(graphs) >= GRAPH_SLOTS:
+            graphs.pop(next(iter(graphs)))
+        ent = graphs[key] = (graph, out, (x, flags, labels, sc, sym_err))   # the recorded addresses stay allocated
+    ent[0].replay()
+    PASS_COUNT += 1
+    GRAPH_REPLAYS += 1
+    return ent[1]
+
+
+_CAPTURE = {}
+
+
+def _capture_stream(device):
+    """Recording stream, one per (device, caller stream): graphs replayed from different streams never share the
+    workspace of an unsplit pass (split passes use the part-batch streams' workspaces, like the eager path)."""
+    idx = device.index if device.index is not None else torch.cuda.current_device()
+    key = (idx, torch.cuda.current_stream(idx).cuda_stream)
+    st = _CAPTURE.get(key)
+    if st is None:
+        st = _CAPTURE[key] = torch.cuda.Stream(device=idx)
+    return st
 
 
 def nodeadj_pass(cache: NetCache, mode: int, adj, node, node_flags, labels, labels_uniform: bool, sc_adj, sc_node,

@@ -29,6 +29,10 @@ class Precond(nn.Module):
         self.symmetry_check = 'deferred'
         self._sym_acc = None
         self._step_memo = None  # set by EDMSampler(reuse_passes=True) for the duration of one Heun step
+        # Opt-in (no reference counterpart): no-grad passes run as HIP-graph replays (engine.graphed_pass).  The caller
+        # keeps x / node_flags / sigmas at fixed addresses and the returned tensor is overwritten by the next call with
+        # the same addresses.  EDMSampler(use_graphs=True) sets this for the duration of sample().
+        self.use_graphs = False
 
     def _acc(self, device):
         if self._sym_acc is None or self._sym_acc.device != device:
@@ -47,6 +51,7 @@ class Precond(nn.Module):
         coin = bool(self.self_condition and np.random.rand() < 0.5)
         acc = None if self.symmetry_check == 'off' else self._acc(x.device)
         memo = None if with_grad else self._step_memo
+        run = E.graphed_pass if (self.use_graphs and not with_grad) else E.network_pass
         if memo is not None:
             # Both model calls of a Heun step evaluate the SAME (x_hat, sigma_hat) (mcmc_sampler/edm.py:183,205) and the
             # passed self_cond is discarded, so the step only ever needs P0 = D(x_hat | no self-cond) and, when a coin
@@ -57,21 +62,20 @@ class Precond(nn.Module):
                 memo["key"] = (x.data_ptr(), tuple(x.shape))
             sc_on = self.model.self_condition
             if "P0" not in memo:
-                memo["P0"] = E.network_pass(cache, 1, x, node_flags, labels, uniform, None, sym_err=acc)
+                memo["P0"] = run(cache, 1, x, node_flags, labels, uniform, None, sym_err=acc)
             if not (coin and sc_on):
                 return memo["P0"]
             if "P1" not in memo:
-                memo["P1"] = E.network_pass(cache, 1, x, node_flags, labels, uniform, memo["P0"], sym_err=acc)
+                memo["P1"] = run(cache, 1, x, node_flags, labels, uniform, memo["P0"], sym_err=acc)
             return memo["P1"]
         if coin:
-            sc = E.network_pass(cache, 1, x, node_flags, labels, uniform, None)
+            sc = run(cache, 1, x, node_flags, labels, uniform, None)
         if with_grad:  # training step (runner/trainer/trainer.py:110): forward that keeps op inputs + HIP backward
             from .train import denoise_with_grad
             D = denoise_with_grad(self.model, 1, x, node_flags, sigmas.expand(x.shape[0]) if uniform else sigmas,
                                   sc if self.model.self_condition else None, acc)
         else:
-            D = E.network_pass(cache, 1, x, node_flags, labels, uniform, sc if self.model.self_condition else None,
-                               sym_err=acc)
+            D = run(cache, 1, x, node_flags, labels, uniform, sc if self.model.self_condition else None, sym_err=acc)
         if self.symmetry_check == 'eager':
             self.assert_symmetric()
         return D

@@ -387,6 +387,40 @@ def test_pass_reuse_is_bit_identical(S, golden_meta):
         print(f"{net_name}: {counts[0]} passes by default, {counts[1]} with reuse ({steps} Heun steps)")
 
 
+def test_graph_replayed_sampler_is_bit_identical(S, golden_meta, monkeypatch):
+    """EDMSampler.use_graphs (opt-in): every network pass is one HIP-graph launch recorded on first use.  Same seeds ->
+    the samples must be bit-identical to the eager run, for the unsplit pass, for the pass recorded with its two
+    part-batch branches, together with reuse_passes, and on a second sample() call that replays the recorded graphs."""
+    from swingnn_amd import engine as E
+    for net_name, steps, B, split in (("ego60", 12, 3, False), ("grid192", 3, 2, True)):
+        nc = NET_CASES[net_name]
+        cfg = nc["cfg"]
+        monkeypatch.setattr(E, "SPLIT_MIN_WORK", 0 if split else 1 << 60)
+        pre = build_precond(S, net_name, golden_meta, "init", seed=7)
+        flags = filler.node_flags("flags", B, cfg["img_size"], nc["n_lo"], nc["n_hi"], 7).to(DEV)
+        outs = {}
+        for name, graphs, reuse in (("eager", False, False), ("graphs", True, False), ("graphs+reuse", True, True)):
+            smp = S.EDMSampler(num_steps=steps, clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
+                               clip_samples_scope="x_0", self_condition=cfg["self_condition"], dev=DEV)
+            smp.use_graphs, smp.reuse_passes = graphs, reuse
+            for call in range(2 if graphs else 1):
+                torch.manual_seed(11)
+                torch.cuda.manual_seed(11)
+                np.random.seed(11)
+                n0, r0 = E.PASS_COUNT, E.GRAPH_REPLAYS
+                outs[(name, call)] = smp.sample(pre, flags)
+                passes, replays = E.PASS_COUNT - n0, E.GRAPH_REPLAYS - r0
+                if graphs:
+                    # the first call also runs one eager pass per recorded graph (at most 3: P0, P0 + symmetry sum, P1)
+                    assert replays > 0 and 0 <= passes - replays <= (3 if call == 0 else 0), (passes, replays)
+            assert not pre.use_graphs                      # the sampler's switch does not outlive sample()
+        ref = outs[("eager", 0)]
+        for k, v in outs.items():
+            assert torch.equal(ref, v), f"{net_name} {k}: max diff {float((ref - v).abs().max())}"
+        pre.assert_symmetric()
+        print(f"{net_name}: graph-replayed sampler bit-identical ({'split' if split else 'one stream'}, {steps} steps)")
+
+
 def test_split_stream_pass_is_bit_identical(S, golden_meta, monkeypatch):
     """engine.network_pass issues a large batch as two part-batches on two streams: same bits as one launch, the
     symmetry accumulator still sees every sample, and the caller's stream is ordered after both parts."""
