@@ -13,20 +13,30 @@ namespace {
 
 constexpr int CHUNK = 2048;  // elements per workgroup: 256 threads x 2 float4
 
+// persistent workgroups over the chunk list (one atomic per WORKGROUP, not per chunk: 17 k same-address atomics were
+// 3/4 of this kernel's time), float4 loads where the chunk is 16-byte aligned
 __global__ __launch_bounds__(256) void k_grad_sqnorm(const float* const* __restrict__ g_ptrs,
                                                      const int32_t* __restrict__ numel,
                                                      const int32_t* __restrict__ chunk_tensor,
-                                                     const int32_t* __restrict__ chunk_off, float* __restrict__ sqnorm) {
+                                                     const int32_t* __restrict__ chunk_off, int n_chunks,
+                                                     float* __restrict__ sqnorm) {
   __shared__ float red[4];
-  const int c = blockIdx.x;
-  const int t = chunk_tensor[c];
-  const int off = chunk_off[c];
-  const int n = min(CHUNK, numel[t] - off);
-  const float* g = g_ptrs[t] + off;
   float s = 0.f;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    const float v = g[i];
-    s += v * v;
+  for (int c = blockIdx.x; c < n_chunks; c += gridDim.x) {
+    const int t = chunk_tensor[c];
+    const int off = chunk_off[c];
+    const int n = min(CHUNK, numel[t] - off);
+    const float* g = g_ptrs[t] + off;
+    if ((reinterpret_cast<uintptr_t>(g) & 15) == 0) {
+      const int n4 = n >> 2;
+      for (int i = threadIdx.x; i < n4; i += 256) {
+        const float4 v = reinterpret_cast<const float4*>(g)[i];
+        s += v.x * v.x + v.y * v.y + v.z * v.z + v.w * v.w;
+      }
+      for (int i = 4 * n4 + threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    } else {
+      for (int i = threadIdx.x; i < n; i += 256) s += g[i] * g[i];
+    }
   }
   s = group_sum<64>(s);
   if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
@@ -65,15 +75,48 @@ __global__ __launch_bounds__(256) void k_adam_ema(AdamArgs a) {
     clip = fminf(a.max_norm / (sqrtf(*a.sqnorm) + 1e-6f), 1.0f);
   }
   const float step = a.lr / a.bc1;
-  for (int i = threadIdx.x; i < n; i += 256) {
-    float pv = p[i];
-    float gv = g[i] * clip;
+  auto update = [&](float& pv, float gv, float& mv, float& vv) {
+    gv *= clip;
     if (a.wd != 0.f) gv = fmaf(a.wd, pv, gv);
-    const float mv = a.b1 * a.m[fo + i] + (1.f - a.b1) * gv;
-    const float vv = a.b2 * a.v[fo + i] + (1.f - a.b2) * gv * gv;
+    mv = a.b1 * mv + (1.f - a.b1) * gv;
+    vv = a.b2 * vv + (1.f - a.b2) * gv * gv;
+    pv -= step * mv / (sqrtf(vv) / a.bc2s + a.eps);
+  };
+  int done = 0;
+  // 16-byte form (same arithmetic per element): parameter, gradient and the flat moment / EMA slices all aligned
+  if (((reinterpret_cast<uintptr_t>(p) | reinterpret_cast<uintptr_t>(g) | reinterpret_cast<uintptr_t>(a.m + fo) |
+        reinterpret_cast<uintptr_t>(a.v + fo) | reinterpret_cast<uintptr_t>(a.ema ? a.ema + fo : nullptr)) & 15) == 0 &&
+      (a.total & 3) == 0) {
+    const int n4 = n >> 2;
+    for (int i = threadIdx.x; i < n4; i += 256) {
+      float4 pv = reinterpret_cast<float4*>(p)[i];
+      const float4 gv = reinterpret_cast<const float4*>(g)[i];
+      float4 mv = reinterpret_cast<float4*>(a.m + fo)[i];
+      float4 vv = reinterpret_cast<float4*>(a.v + fo)[i];
+      update(pv.x, gv.x, mv.x, vv.x);
+      update(pv.y, gv.y, mv.y, vv.y);
+      update(pv.z, gv.z, mv.z, vv.z);
+      update(pv.w, gv.w, mv.w, vv.w);
+      reinterpret_cast<float4*>(a.m + fo)[i] = mv;
+      reinterpret_cast<float4*>(a.v + fo)[i] = vv;
+      reinterpret_cast<float4*>(p)[i] = pv;
+      for (int k = 0; k < a.n_ema; ++k) {
+        float4* e = reinterpret_cast<float4*>(a.ema + (int64_t)k * a.total + fo) + i;
+        float4 ev = *e;
+        ev.x += a.ema_w[k] * (pv.x - ev.x);
+        ev.y += a.ema_w[k] * (pv.y - ev.y);
+        ev.z += a.ema_w[k] * (pv.z - ev.z);
+        ev.w += a.ema_w[k] * (pv.w - ev.w);
+        *e = ev;
+      }
+    }
+    done = 4 * n4;
+  }
+  for (int i = done + threadIdx.x; i < n; i += 256) {
+    float pv = p[i], mv = a.m[fo + i], vv = a.v[fo + i];
+    update(pv, g[i], mv, vv);
     a.m[fo + i] = mv;
     a.v[fo + i] = vv;
-    pv -= step * mv / (sqrtf(vv) / a.bc2s + a.eps);
     p[i] = pv;
     for (int k = 0; k < a.n_ema; ++k) {
       float* e = a.ema + (int64_t)k * a.total + fo + i;
@@ -95,8 +138,8 @@ int swg_grad_sqnorm(const void* g_ptrs, const int32_t* numel, const int32_t* chu
   hipError_t he = hipMemsetAsync(sqnorm, 0, sizeof(float), s);
   if (he != hipSuccess) return (int)he;
   SwgProfScope ps(KID_OPTIM, 0.0, 4.0 * n_chunks * (double)CHUNK, s);
-  hipLaunchKernelGGL(k_grad_sqnorm, dim3(n_chunks), dim3(256), 0, s, (const float* const*)g_ptrs, numel, chunk_tensor,
-                     chunk_off, sqnorm);
+  hipLaunchKernelGGL(k_grad_sqnorm, dim3(min(n_chunks, 2048)), dim3(256), 0, s, (const float* const*)g_ptrs, numel,
+                     chunk_tensor, chunk_off, n_chunks, sqnorm);
   SWG_LAUNCH_CHECK();
   return 0;
 }

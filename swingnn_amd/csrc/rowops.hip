@@ -1015,34 +1015,79 @@ __global__ __launch_bounds__(256) void k_edm_noisy(int N, const float* __restric
   }
 }
 
-// per graph: S_b = w_b * sum_{ij} mask_ij (pred - target)^2 and n_b = sum flags_b (one workgroup per graph, fixed
-// summation order: deterministic)
-__global__ __launch_bounds__(256) void k_edm_loss_sums(int N, const float* __restrict__ pred,
-                                                       const float* __restrict__ target, const float* __restrict__ flags,
-                                                       const float* __restrict__ weights, float* __restrict__ S,
-                                                       float* __restrict__ nn) {
-  __shared__ float red[4];
+// per graph: S_b = w_b * sum_{ij} mask_ij (pred - target)^2 and n_b = sum flags_b (one workgroup of 16 waves per
+// graph, fixed summation order: deterministic).  VEC: N % 4 == 0 and 16-byte aligned planes -> the plane is walked as
+// one flat run of float4 (four loads in flight per lane); the masks of a float4 come from the cached flag row.
+template <bool VEC>
+__global__ __launch_bounds__(1024) void k_edm_loss_sums(int N, const float* __restrict__ pred,
+                                                        const float* __restrict__ target,
+                                                        const float* __restrict__ flags,
+                                                        const float* __restrict__ weights, float* __restrict__ S,
+                                                        float* __restrict__ nn) {
+  __shared__ float red[16];
   const int bi = blockIdx.x;
   const size_t base = (size_t)bi * N * N;
   const float* fl = flags + (size_t)bi * N;
   float acc = 0.f;
-  for (int r = threadIdx.x >> 6; r < N; r += 4) {
-    if (fl[r] == 0.f) continue;
-    for (int c = threadIdx.x & 63; c < N; c += 64) {
-      if (fl[c] == 0.f) continue;
-      const float d = pred[base + (size_t)r * N + c] - target[base + (size_t)r * N + c];
-      acc = fmaf(d, d, acc);
+  if (VEC) {
+    const float4* p4 = reinterpret_cast<const float4*>(pred + base);
+    const float4* t4 = reinterpret_cast<const float4*>(target + base);
+    const int n4 = N * (N / 4);
+    for (int i0 = threadIdx.x; i0 < n4; i0 += 4096) {
+      float4 a[4], b[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        if (i < n4) { a[u] = p4[i]; b[u] = t4[i]; }
+      }
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const int i = i0 + 1024 * u;
+        if (i >= n4) continue;
+        const int r = (4 * i) / N, c = 4 * i - r * N;
+        if (fl[r] == 0.f) continue;
+        const float dx = a[u].x - b[u].x, dy = a[u].y - b[u].y, dz = a[u].z - b[u].z, dw = a[u].w - b[u].w;
+        if (fl[c] != 0.f) acc = fmaf(dx, dx, acc);
+        if (fl[c + 1] != 0.f) acc = fmaf(dy, dy, acc);
+        if (fl[c + 2] != 0.f) acc = fmaf(dz, dz, acc);
+        if (fl[c + 3] != 0.f) acc = fmaf(dw, dw, acc);
+      }
+    }
+  } else {
+    for (int r = threadIdx.x >> 6; r < N; r += 16) {
+      if (fl[r] == 0.f) continue;
+      for (int c = threadIdx.x & 63; c < N; c += 64) {
+        if (fl[c] == 0.f) continue;
+        const float d = pred[base + (size_t)r * N + c] - target[base + (size_t)r * N + c];
+        acc = fmaf(d, d, acc);
+      }
     }
   }
-  const float tot = block_sum_256(acc, red);
   float cnt = 0.f;
-  for (int r = threadIdx.x; r < N; r += 256) cnt += fl[r];
+  for (int r = threadIdx.x; r < N; r += 1024) cnt += fl[r];
+  acc = group_sum<64>(acc);
+  cnt = group_sum<64>(cnt);
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = acc;
   __syncthreads();
-  const float n = block_sum_256(cnt, red);
+  float tot = 0.f;
+  if (threadIdx.x == 0)
+    for (int w = 0; w < 16; ++w) tot += red[w];
+  __syncthreads();
+  if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = cnt;
+  __syncthreads();
   if (threadIdx.x == 0) {
+    float n = 0.f;
+    for (int w = 0; w < 16; ++w) n += red[w];
     S[bi] = tot * (weights ? weights[bi] : 1.0f);
     nn[bi] = n;
   }
+}
+
+static void launch_edm_loss_sums(int B, int N, const float* pred, const float* target, const float* node_flags,
+                                 const float* weights, float* S, float* nn, hipStream_t s) {
+  const bool vec = N % 4 == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target)) & 15) == 0;
+  if (vec) hipLaunchKernelGGL(k_edm_loss_sums<true>, dim3(B), dim3(1024), 0, s, N, pred, target, node_flags, weights, S, nn);
+  else hipLaunchKernelGGL(k_edm_loss_sums<false>, dim3(B), dim3(1024), 0, s, N, pred, target, node_flags, weights, S, nn);
 }
 
 // reduction 'none': loss_b = S_b / n_b^2 * rlw ; reduction 'mean' (rainbow_loss.py:94-96): (sum_b S_b) / n_b^2 * rlw
@@ -1136,8 +1181,7 @@ int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, c
                  float* scratch2B, void* stream) {
   if (!pred || !target || !node_flags || !loss || !scratch2B) return SWG_E_NULL;
   if (B <= 0 || N <= 0) return SWG_E_SHAPE;
-  hipLaunchKernelGGL(k_edm_loss_sums, dim3(B), dim3(256), 0, (hipStream_t)stream, N, pred, target, node_flags, weights,
-                     scratch2B, scratch2B + B);
+  launch_edm_loss_sums(B, N, pred, target, node_flags, weights, scratch2B, scratch2B + B, (hipStream_t)stream);
   hipLaunchKernelGGL(k_edm_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, B, scratch2B, scratch2B + B,
                      regression_loss_weight, reduction_mean, loss);
   SWG_LAUNCH_CHECK();
@@ -1189,8 +1233,7 @@ extern "C" int swg_edm_loss_noalloc(int32_t B, int32_t N, const float* pred, con
   if (rc != 0) return rc;
   // every slot b < B of both halves is overwritten by k_edm_loss_sums before k_edm_loss_finish reads it, so the
   // previous call's contents need no clearing
-  hipLaunchKernelGGL(k_edm_loss_sums, dim3(B), dim3(256), 0, (hipStream_t)stream, N, pred, target, node_flags, weights,
-                     ptr, ptr + SWG_LOSS_NOALLOC_MAX_B);
+  launch_edm_loss_sums(B, N, pred, target, node_flags, weights, ptr, ptr + SWG_LOSS_NOALLOC_MAX_B, (hipStream_t)stream);
   hipLaunchKernelGGL(k_edm_loss_finish, dim3(1), dim3(64), 0, (hipStream_t)stream, B, ptr, ptr + SWG_LOSS_NOALLOC_MAX_B,
                      regression_loss_weight, reduction_mean, loss);
   SWG_LAUNCH_CHECK();
