@@ -543,9 +543,24 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
   if (!P || !Q || !out) return SWG_E_NULL;
   const int tiles_m = cdiv(Mo, 128), tiles_n = cdiv(No, 128);
   const int tiles = tiles_m * tiles_n;
-  int S = min(min(cdiv(512, tiles), max(rows / 256, 1)), 256);  // 2 workgroups per CU: one round
-  int kslice = round_up(cdiv(rows, S), TN_BT);
-  S = cdiv(rows, kslice);
+  // Token slices: slice sl runs on XCD sl % 8 (see k_gemm_tn), 64 workgroup slots per XCD (32 CUs x 2).  With s8
+  // slices per XCD an XCD works through tiles * s8 workgroups in ceil(tiles * s8 / 64) rounds of rows / (8 s8 * 32)
+  // k-steps each, plus a fixed cost per workgroup (prologue + 64 KB of atomics) of about TN_FIXED k-steps: take the
+  // s8 with the least modelled time.  (The former rule, 512 / tiles slices, left XCDs idle whenever that was not a
+  // multiple of 8 and spilled a few workgroups into a second round: C = 768 fc1 159 us, C = 192 fc1 157 us.)
+  static const int forced_s8 = [] { const char* v = getenv("SWG_TN_S8"); return v ? atoi(v) : 0; }();
+  static const int fixed_k = [] { const char* v = getenv("SWG_TN_FIXED"); return v ? atoi(v) : 32; }();
+  int best_s8 = 1;
+  long best_cost = -1;
+  for (int s8 = 1; s8 <= 32; ++s8) {
+    const int ks = round_up(cdiv(rows, 8 * s8), TN_BT);
+    if (ks < 64 && s8 > 1) break;
+    const long cost = (long)cdiv(tiles * s8, 64) * (ks / TN_BT + fixed_k);
+    if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_s8 = s8; }
+  }
+  if (forced_s8 > 0) best_s8 = forced_s8;
+  int kslice = round_up(cdiv(rows, 8 * best_s8), TN_BT);
+  const int S = cdiv(rows, kslice);
   SwgProfScope ps(KID_GEMM_TN, 2.0 * Mo * (double)No * rows, 2.0 * rows * (double)(min(ldp, tiles_m * 128) + min(ldq, tiles_n * 128)) +
                                                            8.0 * Mo * (double)No, s);
   if (S <= 1) {
