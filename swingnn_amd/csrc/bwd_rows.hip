@@ -173,36 +173,43 @@ __global__ __launch_bounds__(256) void k_gelu_bwd_colsum(const bf16* __restrict_
 // perm_res > 0 a row is the PACKED row (b, Y, X) of 4 tokens x Cs channels and the operands named in perm_mask
 // (1: x, 2: dy, 4: dx) live in TOKEN layout [B, perm_res^2, Cs]; chunk c of the row is channel chunk c % (Cs/4) of token
 // (2Y + (k&1), 2X + (k>>1)), k = c / (Cs/4).
-template <int V>
+// LANES lanes per row (64 / LANES rows per wavefront at a time): narrow rows keep every lane busy (C = 96: 8 lanes x 3
+// float4, 8 rows per wave instead of one row on 24 of 64 lanes).
+template <int LANES, int V>
 __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, const float* __restrict__ dy,
                                                 const float* __restrict__ g, const float* __restrict__ dres, int rows,
                                                 int C, float* __restrict__ dx, float* __restrict__ dg,
                                                 float* __restrict__ db, int perm_res, int perm_mask,
                                                 bf16* __restrict__ dxb) {
   extern __shared__ __attribute__((aligned(16))) float red[];  // [2][C]
+  constexpr int RPW = 64 / LANES;  // rows per wavefront
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int gl = lane % LANES, grp = lane / LANES;
   const int nch = C >> 2;
   float4 ag[V], ab[V], gg[V];
 #pragma unroll
   for (int i = 0; i < V; ++i) {
     ag[i] = ab[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-    const int c = lane + 64 * i;
+    const int c = gl + LANES * i;
     gg[i] = (c < nch) ? *reinterpret_cast<const float4*>(g + 4 * c) : make_float4(0.f, 0.f, 0.f, 0.f);
   }
+  for (int c = threadIdx.x; c < 2 * C; c += 256) red[c] = 0.f;
   const float invC = 1.0f / (float)C;
   const int pcs = nch >> 2, r2 = perm_res >> 1;  // chunks per token; packed grid side
-  for (int row = blockIdx.x * 4 + wave; row < rows; row += gridDim.x * 4) {
+  for (int row0 = (blockIdx.x * 4 + wave) * RPW; row0 < rows; row0 += gridDim.x * 4 * RPW) {
+    const int row = row0 + grp;
+    const bool live = row < rows;
     float4 xv[V], dv[V];
     float s = 0.f;
     size_t ptok = 0;  // token (2Y, 2X) of the packed row
-    if (perm_res) {
+    if (perm_res && live) {
       const int X = row % r2, t = row / r2, Y = t % r2, b = t / r2;
       ptok = ((size_t)b * perm_res + 2 * Y) * perm_res + 2 * X;
     }
     size_t po[V];  // element offset of chunk i in token layout
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const int c = lane + 64 * i;
+      const int c = gl + LANES * i;
       po[i] = 0;
       if (perm_res && c < nch) {
         const int k = c / pcs, cc = c - k * pcs;
@@ -211,23 +218,23 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
     }
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const int c = lane + 64 * i;
+      const int c = gl + LANES * i;
       xv[i] = dv[i] = make_float4(0.f, 0.f, 0.f, 0.f);
-      if (c < nch) {
+      if (live && c < nch) {
         xv[i] = *reinterpret_cast<const float4*>(x + ((perm_mask & 1) ? po[i] : (size_t)row * C + 4 * c));
         dv[i] = *reinterpret_cast<const float4*>(dy + ((perm_mask & 2) ? po[i] : (size_t)row * C + 4 * c));
       }
       s += (xv[i].x + xv[i].y) + (xv[i].z + xv[i].w);
     }
-    const float mean = group_sum<64>(s) * invC;
+    const float mean = group_sum<LANES>(s) * invC;
     float q = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i)
-      if (lane + 64 * i < nch) {
+      if (gl + LANES * i < nch) {
         xv[i].x -= mean; xv[i].y -= mean; xv[i].z -= mean; xv[i].w -= mean;
         q += (xv[i].x * xv[i].x + xv[i].y * xv[i].y) + (xv[i].z * xv[i].z + xv[i].w * xv[i].w);
       }
-    const float rstd = ln_rstd(group_sum<64>(q) * invC);
+    const float rstd = ln_rstd(group_sum<LANES>(q) * invC);
     float s1 = 0.f, s2 = 0.f;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
@@ -238,11 +245,11 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
       s1 += (dv[i].x + dv[i].y) + (dv[i].z + dv[i].w);
       s2 += (dv[i].x * xv[i].x + dv[i].y * xv[i].y) + (dv[i].z * xv[i].z + dv[i].w * xv[i].w);
     }
-    const float m1 = group_sum<64>(s1) * invC, m2 = group_sum<64>(s2) * invC;
+    const float m1 = group_sum<LANES>(s1) * invC, m2 = group_sum<LANES>(s2) * invC;
 #pragma unroll
     for (int i = 0; i < V; ++i) {
-      const int c = lane + 64 * i;
-      if (c < nch) {
+      const int c = gl + LANES * i;
+      if (live && c < nch) {
         float4 o;
         o.x = rstd * (dv[i].x - m1 - xv[i].x * m2); o.y = rstd * (dv[i].y - m1 - xv[i].y * m2);
         o.z = rstd * (dv[i].z - m1 - xv[i].z * m2); o.w = rstd * (dv[i].w - m1 - xv[i].w * m2);
@@ -255,22 +262,21 @@ __global__ __launch_bounds__(256) void k_ln_bwd(const float* __restrict__ x, con
       }
     }
   }
-  // fold the four waves' column partials through LDS, then one atomic per column per workgroup
-  for (int w = 0; w < 4; ++w) {
-    if (wave == w) {
+  // fold the column partials of the 4 x RPW row groups through LDS (one group after the other: a fixed order inside
+  // the workgroup), then one atomic per column per workgroup
+  __syncthreads();
+  for (int w = 0; w < 4 * RPW; ++w) {
+    if (wave * RPW + grp == w) {
 #pragma unroll
       for (int i = 0; i < V; ++i) {
-        const int c = lane + 64 * i;
+        const int c = gl + LANES * i;
         if (c < nch) {
           float4* pg = reinterpret_cast<float4*>(red + 4 * c);
           float4* pb = reinterpret_cast<float4*>(red + C + 4 * c);
-          if (w == 0) { *pg = ag[i]; *pb = ab[i]; }
-          else {
-            float4 a = *pg, b = *pb;
-            a.x += ag[i].x; a.y += ag[i].y; a.z += ag[i].z; a.w += ag[i].w;
-            b.x += ab[i].x; b.y += ab[i].y; b.z += ab[i].z; b.w += ab[i].w;
-            *pg = a; *pb = b;
-          }
+          float4 a = *pg, b = *pb;
+          a.x += ag[i].x; a.y += ag[i].y; a.z += ag[i].z; a.w += ag[i].w;
+          b.x += ab[i].x; b.y += ab[i].y; b.z += ab[i].z; b.w += ab[i].w;
+          *pg = a; *pb = b;
         }
       }
     }
@@ -676,19 +682,24 @@ int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* 
   if (perm_res && (C % 16 || perm_res % 2 || dres)) return SWG_E_SHAPE;
   if (!perm_res) perm_mask = 0;
   if (!x || !dy || !g || !dx || !dg || !db) return SWG_E_NULL;
-  const int V = cdiv(C / 4, 64);
-  const int grid = min(cdiv(rows, 4), 1024);
+  const int nch = C / 4;
+  const int lanes = nch <= 32 ? 8 : nch <= 64 ? 16 : nch <= 128 ? 32 : 64;
+  const int grid = min(cdiv(rows, 4 * (64 / lanes)), 1024);
   const size_t lds = (size_t)2 * C * sizeof(float);
   SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)rows * C * (dres ? 16.0 : 12.0), s);
-#define LNB(VV) \
-  hipLaunchKernelGGL((k_ln_bwd<VV>), dim3(grid), dim3(256), lds, s, x, dy, g, dres, rows, C, dx, dg, db, perm_res, perm_mask, dx_bf16)
-  if (V <= 1) LNB(1);
-  else if (V == 2) LNB(2);
-  else if (V == 3) LNB(3);
-  else if (V == 4) LNB(4);
-  else if (V <= 6) LNB(6);
-  else if (V <= 8) LNB(8);
-  else LNB(12);
+#define LNB(LN, VV) \
+  hipLaunchKernelGGL((k_ln_bwd<LN, VV>), dim3(grid), dim3(256), lds, s, x, dy, g, dres, rows, C, dx, dg, db, perm_res, perm_mask, dx_bf16)
+  if (nch <= 24) LNB(8, 3);
+  else if (nch <= 32) LNB(8, 4);
+  else if (nch <= 48) LNB(16, 3);
+  else if (nch <= 64) LNB(16, 4);
+  else if (nch <= 96) LNB(32, 3);
+  else if (nch <= 128) LNB(32, 4);
+  else if (nch <= 192) LNB(64, 3);
+  else if (nch <= 256) LNB(64, 4);
+  else if (nch <= 384) LNB(64, 6);
+  else if (nch <= 512) LNB(64, 8);
+  else LNB(64, 12);
 #undef LNB
   SWG_LAUNCH_CHECK();
   return 0;
