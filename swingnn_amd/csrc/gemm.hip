@@ -550,11 +550,12 @@ int launch_gemm_tn_splitk(const bf16* P, int ldp, const bf16* Q, int ldq, int ro
   // multiple of 8 and spilled a few workgroups into a second round: C = 768 fc1 159 us, C = 192 fc1 157 us.)
   static const int forced_s8 = [] { const char* v = getenv("SWG_TN_S8"); return v ? atoi(v) : 0; }();
   static const int fixed_k = [] { const char* v = getenv("SWG_TN_FIXED"); return v ? atoi(v) : 32; }();
+  static const int min_ks = [] { const char* v = getenv("SWG_TN_MINK"); return v ? atoi(v) : 256; }();
   int best_s8 = 1;
   long best_cost = -1;
   for (int s8 = 1; s8 <= 32; ++s8) {
     const int ks = round_up(cdiv(rows, 8 * s8), TN_BT);
-    if (ks < 64 && s8 > 1) break;
+    if (ks < min_ks && s8 > 1) break;  // short slices: the atomics of many workgroups on one tile cost more than they save
     const long cost = (long)cdiv(tiles * s8, 64) * (ks / TN_BT + fixed_k);
     if (best_cost < 0 || cost < best_cost) { best_cost = cost; best_s8 = s8; }
   }
