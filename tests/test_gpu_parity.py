@@ -421,6 +421,35 @@ def test_graph_replayed_sampler_is_bit_identical(S, golden_meta, monkeypatch):
         print(f"{net_name}: graph-replayed sampler bit-identical ({'split' if split else 'one stream'}, {steps} steps)")
 
 
+def test_recorded_graphs_follow_parameter_updates(S, golden_meta):
+    """The recorded nodes bake kernel arguments (the collapsed read-out bias among them): after the parameters change
+    in place (optimizer step, load_state_dict) the derived operands are refreshed and the graphs re-recorded, so a
+    graph-replayed pass equals the eager pass with the NEW parameters."""
+    from swingnn_amd import engine as E
+    nc = NET_CASES["ego60"]
+    cfg = nc["cfg"]
+    pre = build_precond(S, "ego60", golden_meta, "init", seed=7)
+    B, N = 3, cfg["img_size"]
+    flags = filler.node_flags("flags", B, N, nc["n_lo"], nc["n_hi"], 5).to(DEV)
+    x = filler.sym_adj("x", B, N, flags.cpu(), 5, 2.0).to(DEV)
+    sig = torch.full((1,), 0.9, device=DEV)
+    np.random.seed(1)
+    pre.use_graphs = True
+    first = pre(x, flags, sig.expand(B)).clone()
+    gen0 = E.get_cache(pre.model).generation
+    with torch.no_grad():
+        for p in pre.model.parameters():
+            p.add_(0.01 * torch.sign(p))
+    np.random.seed(1)
+    replayed = pre(x, flags, sig.expand(B)).clone()
+    assert E.get_cache(pre.model).generation == gen0 + 1
+    pre.use_graphs = False
+    np.random.seed(1)
+    eager = pre(x, flags, sig.expand(B))
+    assert torch.equal(replayed, eager), float((replayed - eager).abs().max())
+    assert not torch.equal(first, replayed)
+
+
 def test_split_stream_pass_is_bit_identical(S, golden_meta, monkeypatch):
     """engine.network_pass issues a large batch as two part-batches on two streams: same bits as one launch, the
     symmetry accumulator still sees every sample, and the caller's stream is ordered after both parts."""
