@@ -279,6 +279,7 @@ int launch_mlp_bwd_front(int C, int T, const float* x, const float* dy, const bf
                          const float* b, bf16* xn, bf16* dyb, int ldc, bf16* act, bf16* dh, int ldh, float* part,
                          hipStream_t s);
 size_t mlp_bwd_front_part_floats(int C, int T);
+int mlp_bwd_front_tokens_per_wg(int C);
 bool ln_cond_bwd_supported(int C);
 int launch_ln_cond_bwd(const float* x, const float* dxn, const float* dres, const float* g, const float* cond,
                        int cond_stride, int cond_off, int B, int L, int C, float* dx, float* dg, float* db, float* dcond,

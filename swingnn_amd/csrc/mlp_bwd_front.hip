@@ -1,5 +1,5 @@
 // Front half of the MLP backward of a Swin block (model/swin_gnn/swin_gnn.py:275 with Mlp :19-25) in ONE pass over the
-// token rows, for the narrow stages (C = 96, 192) where every tensor of the unfused chain is HBM-bound:
+// token rows, for C = 96, 192, 384 (every hidden-sized tensor of the unfused chain crosses HBM several times):
 //     xn = LN2(x)            h  = xn W1^T + b1          a  = GELU(h)
 //     da = dy W2             dh = da * GELU'(h)
 // Outputs are the four bf16 GEMM operands the rest of the backward needs -- xn and dy (C wide), a and dh (4C wide);
@@ -36,9 +36,11 @@ __device__ __forceinline__ void wait_vm() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
-// HC: hidden features per chunk (64 at C = 96, 32 at C = 192: two resident workgroups per CU either way)
-template <int C, int HC>
-__global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
+// HC: hidden features per chunk (64 at C = 96, 32 at C = 192, 16 at C = 384: two resident workgroups per CU each way)
+// MT: 16-token row tiles per wave (2: 128 tokens per workgroup; 3 at C = 384: 192 tokens, one workgroup per CU with the
+// whole register file -- 46080 tokens are then ONE round of 240 workgroups instead of 1.4 rounds of 360)
+template <int C, int HC, int WGS, int MT>
+__global__ __launch_bounds__(256, WGS) void k_mlp_bwd_front(FrontArgs a) {
   constexpr int KS = C / 32;
   constexpr int HT = HC / 16;
   constexpr int NCH = 4 * C / HC;
@@ -49,7 +51,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
-  const int tok0 = blockIdx.x * 128 + wave * 32;
+  const int tok0 = blockIdx.x * (64 * MT) + wave * (16 * MT);
 
   auto stage = [&](int hc, int buf) {
     const char* src = reinterpret_cast<const char*>(a.img) + (size_t)hc * CHUNK_BYTES;
@@ -66,14 +68,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
   for (int i = tid; i < 5 * C; i += 256) ssum[i] = 0.f;
 
   // ---- the wave's 32 rows of x (LayerNorm2 -> operand fragments, also stored) and of dy (cast, also stored) ----
-  bf16x8 xa[2][KS], da[2][KS];
-  float dsum[KS][8];
+  bf16x8 xa[MT][KS], da[MT][KS];
+  __syncthreads();  // ssum is zero before the first column sums go in
 #pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) dsum[ks][e] = 0.f;
-#pragma unroll
-  for (int mt = 0; mt < 2; ++mt) {
+  for (int mt = 0; mt < MT; ++mt) {
     // rows past the end are clamped to the last row: such lanes compute and STORE that row's values again (identical
     // bytes), so every wave issues the same number of stores -- the counted wait in the chunk loop relies on it
     const int tok = tok0 + mt * 16 + l15;
@@ -95,7 +93,16 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
         v[ks][e] = p0[e]; v[ks][4 + e] = p1[e];
         s += p0[e] + p1[e];
         f[e] = (bf16)d0[e]; f[4 + e] = (bf16)d1[e];
-        dsum[ks][e] += live * d0[e]; dsum[ks][4 + e] += live * d1[e];
+      }
+      // column sums of dy (fc2 bias gradient) over the 16 tokens of this lane group, straight into the LDS sums (a
+      // register array over both row tiles would cost KS * 8 registers for the whole kernel)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float t0 = row16_sum(live * d0[e]), t1 = row16_sum(live * d1[e]);
+        if (l15 == 0) {
+          atomicAdd(&ssum[4 * C + 32 * ks + 8 * lg + e], t0);
+          atomicAdd(&ssum[4 * C + 32 * ks + 8 * lg + 4 + e], t1);
+        }
       }
       da[mt][ks] = f;
       *reinterpret_cast<bf16x8*>(a.dyb + (size_t)tc * a.ldc + 32 * ks + 8 * lg) = f;
@@ -125,9 +132,9 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
       *reinterpret_cast<bf16x8*>(a.xn + (size_t)tc * a.ldc + 32 * ks + 8 * lg) = f;
     }
   }
-  float live2[2];
+  float live2[MT];
 #pragma unroll
-  for (int mt = 0; mt < 2; ++mt) live2[mt] = (tok0 + mt * 16 + l15 < a.T) ? 1.0f : 0.0f;
+  for (int mt = 0; mt < MT; ++mt) live2[mt] = (tok0 + mt * 16 + l15 < a.T) ? 1.0f : 0.0f;
 
   int w_off[HT];  // row nt*16 + l15 of an HC-row part, k-step 0; k-step s adds HC*64 bytes; the W2^T part adds HC*C*2
 #pragma unroll
@@ -138,19 +145,19 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
 
   for (int hc = 0; hc < NCH; ++hc) {
     const int buf = hc & 1;
-    // chunk hc has landed: its LDS-DMA pieces are older than the 4 HT stores of the previous iteration, which may stay
+    // chunk hc has landed: its LDS-DMA pieces are older than the 2 MT HT stores of the previous iteration, which may stay
     // in flight (a vmcnt(0) here would expose a store latency per chunk)
     if (hc == 0) wait_vm<0>();
-    else wait_vm<4 * HT>();
+    else wait_vm<2 * MT * HT>();
     __syncthreads();
     if (hc + 1 < NCH) stage(hc + 1, buf ^ 1);
     const char* cb = smem + buf * CHUNK_BYTES;
 
-    f32x4 h[HT][2], d[HT][2];
+    f32x4 h[HT][MT], d[HT][MT];
 #pragma unroll
     for (int nt = 0; nt < HT; ++nt)
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) h[nt][mt] = d[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < MT; ++mt) h[nt][mt] = d[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
     bf16x8 w1f[2][HT], w2f[2][HT];
 #pragma unroll
     for (int nt = 0; nt < HT; ++nt) {
@@ -169,7 +176,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
 #pragma unroll
       for (int nt = 0; nt < HT; ++nt)
 #pragma unroll
-        for (int mt = 0; mt < 2; ++mt) {
+        for (int mt = 0; mt < MT; ++mt) {
           h[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w1f[ks & 1][nt], xa[mt][ks], h[nt][mt], 0, 0, 0);
           d[nt][mt] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w2f[ks & 1][nt], da[mt][ks], d[nt][mt], 0, 0, 0);
         }
@@ -184,7 +191,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
     for (int nt = 0; nt < HT; ++nt) {
       const f32x4 bb = *reinterpret_cast<const f32x4*>(sb1 + hc * HC + nt * 16 + 4 * lg);
 #pragma unroll
-      for (int mt = 0; mt < 2; ++mt) {
+      for (int mt = 0; mt < MT; ++mt) {
         float av[4], gv[4];
 #pragma unroll
         for (int r = 0; r < 4; ++r) {
@@ -219,31 +226,26 @@ __global__ __launch_bounds__(256, 2) void k_mlp_bwd_front(FrontArgs a) {
         if (l15 == 0) atomicAdd(&ssum[hc * HC + nt * 16 + 4 * lg + r], t);
       }
   }
-#pragma unroll
-  for (int ks = 0; ks < KS; ++ks)
-#pragma unroll
-    for (int e = 0; e < 8; ++e) {
-      const float t = row16_sum(dsum[ks][e]);
-      if (l15 == 0) atomicAdd(&ssum[4 * C + 32 * ks + 8 * lg + e], t);
-    }
   __syncthreads();
   for (int i = tid; i < 5 * C; i += 256) a.part[(size_t)blockIdx.x * (5 * C) + i] = ssum[i];
 }
 
-template <int C, int HC>
+template <int C, int HC, int WGS, int MT>
 int launch_c(const FrontArgs& a, hipStream_t s) {
   constexpr size_t lds = (size_t)2 * (2 * HC * C * 2) + (size_t)9 * C * sizeof(float);
   static std::atomic<uint64_t> lds_ok{0};
-  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_bwd_front<C, HC>, (int)lds)) return e;
-  hipLaunchKernelGGL((k_mlp_bwd_front<C, HC>), dim3(cdiv(a.T, 128)), dim3(256), lds, s, a);
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_bwd_front<C, HC, WGS, MT>, (int)lds)) return e;
+  hipLaunchKernelGGL((k_mlp_bwd_front<C, HC, WGS, MT>), dim3(cdiv(a.T, 64 * MT)), dim3(256), lds, s, a);
   return 0;
 }
 
 }  // namespace
 
-bool mlp_bwd_front_supported(int C) { return C == 96 || C == 192; }
+bool mlp_bwd_front_supported(int C) { return C == 96 || C == 192 || C == 384; }
 // floats of the per-workgroup column-sum buffer `part` ([workgroups, 5C]: sums of dh, then of dy)
-size_t mlp_bwd_front_part_floats(int C, int T) { return (size_t)cdiv(T, 128) * 5 * C; }
+// tokens per workgroup (= rows of `part` per 5C floats)
+int mlp_bwd_front_tokens_per_wg(int C) { return C == 384 ? 192 : 128; }
+size_t mlp_bwd_front_part_floats(int C, int T) { return (size_t)cdiv(T, mlp_bwd_front_tokens_per_wg(C)) * 5 * C; }
 
 int launch_mlp_bwd_front(int C, int T, const float* x, const float* dy, const bf16* img, const float* b1, const float* g,
                          const float* b, bf16* xn, bf16* dyb, int ldc, bf16* act, bf16* dh, int ldh, float* part,
@@ -254,7 +256,7 @@ int launch_mlp_bwd_front(int C, int T, const float* x, const float* dy, const bf
   if (ldc < C || ldc % 8 || ldh < 4 * C || ldh % 4) return SWG_E_SHAPE;
   FrontArgs a = {x, dy, img, b1, g, b, xn, dyb, act, dh, part, T, ldc, ldh};
   SwgProfScope ps(KID_BWD_ROWS, 8.0 * T * (double)C * C * 2.0, 8.0 * T * (double)C + 4.0 * T * (double)C + 16.0 * T * (double)C, s);
-  int rc = (C == 96) ? launch_c<96, 64>(a, s) : launch_c<192, 32>(a, s);
+  int rc = (C == 96) ? launch_c<96, 64, 2, 2>(a, s) : (C == 192) ? launch_c<192, 32, 2, 2>(a, s) : launch_c<384, 32, 1, 3>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();
   return 0;

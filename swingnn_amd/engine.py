@@ -207,7 +207,7 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch
     return torch.cat([a, b], dim=1).to(dtype).contiguous()
 
 
-MLP_BWD_FRONT_HC = {96: 64, 192: 32}   # hidden chunk width of csrc/mlp_bwd_front.hip per channel count
+MLP_BWD_FRONT_HC = {96: 64, 192: 32, 384: 32}   # hidden chunk width of csrc/mlp_bwd_front.hip per channel count
 
 
 def mlp_bwd_front_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch.Tensor:
@@ -224,7 +224,7 @@ def mlp_bwd_front_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16
     return torch.cat(parts, dim=1).to(dtype).contiguous()
 
 
-MLP_BWD_FRONT_DIMS = (96, 192)   # channel counts with the fused front half of the MLP backward
+MLP_BWD_FRONT_DIMS = (96, 192, 384)   # channel counts with the fused front half of the MLP backward
 STREAM_MLP_HC = {384: 32, 192: 32}  # hidden chunk width of csrc/mlp_stream.hip per channel count
 
 

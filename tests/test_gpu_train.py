@@ -322,7 +322,8 @@ def test_gradient_sync_sends_only_finished_slices(golden_meta, name, monkeypatch
 
 
 def test_mlp_backward_front_kernel_matches_unfused_chain(golden_meta, monkeypatch):
-    """C = 96 / 192 blocks run the front half of the MLP backward as one kernel (mlp_bwd_front.hip).  With the weight
+    """C = 96 / 192 / 384 blocks run the front half of the MLP backward as one kernel (mlp_bwd_front.hip; 192-token
+    workgroups at C = 384).  With the weight
     images withheld the same step takes the unfused chain (LayerNorm, fc1 GEMM, cast, fc2^T GEMM, GELU pass): the two
     must give the same gradients up to the bf16 rounding of h, which only the unfused chain stores."""
     import swingnn_amd as S
@@ -336,7 +337,7 @@ def test_mlp_backward_front_kernel_matches_unfused_chain(golden_meta, monkeypatc
     def grads(fused):
         pre = build_precond(S, "grid192", golden_meta, "init").train()
         tc = T.get_train_cache(pre.model, E.get_cache(pre.model))
-        assert any(k for k in tc.mlp_bwd_img), "grid192 has C = 96 and C = 192 blocks"
+        assert len(tc.mlp_bwd_img) >= 6, "grid192 has C = 96, 192 and 384 blocks on this path"
         if not fused:
             tc.mlp_bwd_img = {}
         with torch.enable_grad():
@@ -346,6 +347,54 @@ def test_mlp_backward_front_kernel_matches_unfused_chain(golden_meta, monkeypatc
 
     a, b = grads(True), grads(False)
     total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in b.values())))
+    for k in b:
+        rel = float((a[k] - b[k]).norm()) / max(float(b[k].norm()), 1e-3 * total)
+        assert rel <= 2e-2, (k, rel)
+
+
+@pytest.mark.parametrize("N,B,window", [(384, 32, 6), (512, 17, 8)])
+def test_mlp_backward_front_kernel_c384_full_size(monkeypatch, N, B, window):
+    """The C = 384 instance of the MLP-backward front kernel (192-token workgroups, streamed weights) is only taken
+    from 16384 tokens upwards, which the small golden nets never reach: one train step on the bench geometries (grid
+    N = 384: 32 graphs x 576 tokens = 96 full workgroups; DD N = 512: 17 graphs x 1024 tokens = 90 workgroups and a
+    ragged one of 128 tokens) with the kernel, and one with the weight images withheld (unfused chain: LayerNorm, fc1
+    GEMM, cast, fc2^T GEMM, GELU pass).  Same gradients up to the bf16 rounding of h, which only the unfused chain
+    stores."""
+    import swingnn_amd as S
+    from oracle import filler
+    from swingnn_amd import engine as E, train as T
+    net = S.SwinGNN(img_size=N, patch_size=4, in_chans=1, embed_dim=96, depths=[1, 1, 3, 1], num_heads=[3, 6, 12, 24],
+                    window_size=window, mlp_ratio=4., drop_rate=0., attn_drop_rate=0., drop_path_rate=0.0, self_condition=True)
+    pre = S.Precond("edm", net, True)
+    pre.load_state_dict(filler.fill_state_dict(pre.state_dict(), 97, "init"))
+    pre = pre.to(DEV).train()
+    n_nodes = torch.tensor([N - 23 - 9 * (i % 4) for i in range(B)])
+    flags = (torch.arange(N)[None, :] < n_nodes[:, None]).to(torch.float32)
+    sig = torch.tensor([0.1 + 0.3 * i for i in range(B)], dtype=torch.float32)
+    x = torch.cat([filler.sym_adj("x", 1, N, flags[i:i + 1], 300 + i, scale=float(np.sqrt(float(sig[i]) ** 2 + 0.25)))
+                   for i in range(B)])
+    clean = torch.cat([filler.sym_adj("c", 1, N, flags[i:i + 1], 400 + i, scale=1.0) for i in range(B)]).sign()
+    flags, sig, x, clean = flags.to(DEV), sig.to(DEV), x.to(DEV), clean.to(DEV)
+    loss_fn = S.RainbowLoss(1.0, False, "edm")
+    monkeypatch.setattr(np.random, "rand", lambda: 0.75)
+    tc = T.get_train_cache(pre.model, E.get_cache(pre.model))
+    images = dict(tc.mlp_bwd_img)
+    assert sum(1 for k in images if k.startswith(("down_layers.2", "up_layers.1"))) >= 3, sorted(images)
+
+    def grads(fused):
+        tc.mlp_bwd_img = dict(images) if fused else {}
+        pre.zero_grad(set_to_none=True)
+        with torch.enable_grad():
+            D = pre(x=x, node_flags=flags, sigmas=sig)
+            loss_fn(D, clean, sig, x, clean, flags, loss_weight=None, reduction='none').mean().backward()
+        return {k: p.grad.detach().clone() for k, p in pre.named_parameters()}
+
+    try:
+        a, b = grads(True), grads(False)
+    finally:
+        tc.mlp_bwd_img = images
+    total = float(torch.sqrt(sum((g.double() ** 2).sum() for g in b.values())))
+    assert total > 0 and all(torch.isfinite(g).all() for g in a.values())
     for k in b:
         rel = float((a[k] - b[k]).norm()) / max(float(b[k].norm()), 1e-3 * total)
         assert rel <= 2e-2, (k, rel)
