@@ -249,6 +249,7 @@ int embed_bwd_impl(const swg_net* net, const swg_ends_train* tr, int B, const fl
   float* u = cv.take<float>((size_t)T * C0);
   float* un = cv.take<float>((size_t)T * C0);
   float* dun = cv.take<float>((size_t)T * C0);
+  bf16* dunb = cv.take<bf16>((size_t)T * C0);
   float* tmp = cv.take<float>((size_t)C0 * Kp);
   WgradScratch w = take_wgrad(cv, C0, Kp, T);
   if (cv.measure) return 0;
@@ -263,9 +264,17 @@ int embed_bwd_impl(const swg_net* net, const swg_ends_train* tr, int B, const fl
   if ((r = launch_ln_f32(u, T, C0, net->pe_ln.g, net->pe_ln.b, un, s))) return r;
   // ---- conditioning, LayerNorm, conv weight / bias ----
   if ((r = launch_cond_bwd(un, dtok, cond, cond_stride, net->pe_cond_off, B, L, C0, dun, dcond, dcond_stride, s))) return r;
-  if ((r = launch_ln_bwd(u, dun, net->pe_ln.g, nullptr, T, C0, dun, tr->pe_ln.dg, tr->pe_ln.db, s))) return r;
+  // the LayerNorm backward writes its result as the bf16 token-major operand of the weight-gradient GEMM, which also
+  // sums it over the tokens (conv bias gradient): no transposed copies, no 64-workgroup split-K GEMM, no column-sum pass
+  // (row stride C0 must be a multiple of 8 for that GEMM: dim-60 nets keep the transposed-copy route)
   hipError_t he = hipMemsetAsync(tmp, 0, (size_t)C0 * Kp * sizeof(float), s);
   if (he != hipSuccess) return (int)he;
+  if (C0 % 8 == 0) {
+    if ((r = launch_ln_bwd(u, dun, net->pe_ln.g, nullptr, T, C0, nullptr, tr->pe_ln.dg, tr->pe_ln.db, s, 0, 0, dunb))) return r;
+    if ((r = wgrad_tn(dunb, C0, C0, P, Kp, Kp, T, tmp, w, s, tr->dpe_b))) return r;
+    return launch_add_slice(tmp, C0, kin, Kp, tr->dpe_w, s);
+  }
+  if ((r = launch_ln_bwd(u, dun, net->pe_ln.g, nullptr, T, C0, dun, tr->pe_ln.dg, tr->pe_ln.db, s))) return r;
   if ((r = wgrad(dun, nullptr, C0, C0, P, Kp, Kp, T, tmp, w, s))) return r;
   if ((r = launch_add_slice(tmp, C0, kin, Kp, tr->dpe_w, s))) return r;
   return launch_colsum_f32(dun, T, C0, C0, tr->dpe_b, s);
@@ -307,6 +316,7 @@ int na_embed_bwd_impl(const swg_net* net, const swg_nodeadj* na, const swg_ends_
   float* u = cv.take<float>((size_t)T * C0);
   float* un = cv.take<float>((size_t)T * C0);
   float* dun = cv.take<float>((size_t)T * C0);
+  bf16* dunb = cv.take<bf16>((size_t)T * C0);
   float* tmp = cv.take<float>((size_t)C0 * Kp);
   WgradScratch w = take_wgrad(cv, C0, Kp, T);
   if (cv.measure) return 0;
@@ -319,9 +329,17 @@ int na_embed_bwd_impl(const swg_net* net, const swg_nodeadj* na, const swg_ends_
   if ((r = launch_gemm(P, Kp, (const bf16*)tr->pe_wb, T, C0, Kp, e, s))) return r;
   if ((r = launch_ln_f32(u, T, C0, net->pe_ln.g, net->pe_ln.b, un, s))) return r;
   if ((r = launch_cond_bwd(un, dtok, cond, cond_stride, net->pe_cond_off, B, L, C0, dun, dcond, dcond_stride, s))) return r;
-  if ((r = launch_ln_bwd(u, dun, net->pe_ln.g, nullptr, T, C0, dun, tr->pe_ln.dg, tr->pe_ln.db, s))) return r;
+  // the LayerNorm backward writes its result as the bf16 token-major operand of the weight-gradient GEMM, which also
+  // sums it over the tokens (conv bias gradient): no transposed copies, no 64-workgroup split-K GEMM, no column-sum pass
+  // (row stride C0 must be a multiple of 8 for that GEMM: dim-60 nets keep the transposed-copy route)
   hipError_t he = hipMemsetAsync(tmp, 0, (size_t)C0 * Kp * sizeof(float), s);
   if (he != hipSuccess) return (int)he;
+  if (C0 % 8 == 0) {
+    if ((r = launch_ln_bwd(u, dun, net->pe_ln.g, nullptr, T, C0, nullptr, tr->pe_ln.dg, tr->pe_ln.db, s, 0, 0, dunb))) return r;
+    if ((r = wgrad_tn(dunb, C0, C0, P, Kp, Kp, T, tmp, w, s, tr->dpe_b))) return r;
+    return launch_add_slice(tmp, C0, kin, Kp, tr->dpe_w, s);
+  }
+  if ((r = launch_ln_bwd(u, dun, net->pe_ln.g, nullptr, T, C0, dun, tr->pe_ln.dg, tr->pe_ln.db, s))) return r;
   if ((r = wgrad(dun, nullptr, C0, C0, P, Kp, Kp, T, tmp, w, s))) return r;
   if ((r = launch_add_slice(tmp, C0, kin, Kp, tr->dpe_w, s))) return r;
   return launch_colsum_f32(dun, T, C0, C0, tr->dpe_b, s);
