@@ -312,7 +312,12 @@ int launch_wattn_bwd(const bf16* qkv, int ldq, const bf16* dO, int ldo, int B, i
   if (!qkv || !dO || !dqkv || !rpb || !drpb) return SWG_E_NULL;
   WbArgs a = {qkv, ldq, dO, ldo, dqkv, lddq, rpb, drpb, B, res, win, shift, heads, C, hd, 1.0f / sqrtf((float)hd)};
   const int nW = (res / win) * (res / win);
-  const int gy = max(1, min(B * nW, cdiv(4096, heads)));
+  // A workgroup (= one wave) walks over windows of its head.  About `target` workgroups in all, and every one the same
+  // number k of windows (gy = ceil(B nW / k)): with 4096 / heads rows the C = 384 stage of grid B = 80 gave its
+  // workgroups 4 or 3 windows (1280 windows over 342 rows) and the kernel ended on a quarter-empty tail.
+  static const int target = [] { const char* v = getenv("SWG_WBWD_WGS"); return v ? atoi(v) : 3072; }();
+  const int k = max(1, (int)(((long)B * nW * heads + target / 2) / target));
+  const int gy = cdiv(B * nW, k);
   const double T = (double)B * res * res;
   SwgProfScope ps(KID_WATTN_BWD, 10.0 * n * C * T, T * (3.0 * C * 2 + C * 2 + 3.0 * C * 2), s);
   const dim3 grid(heads, gy), block(64);
