@@ -684,7 +684,8 @@ int launch_ln_bwd(const float* x, const float* dy, const float* g, const float* 
   if (!x || !dy || !g || !dx || !dg || !db) return SWG_E_NULL;
   const int nch = C / 4;
   const int lanes = nch <= 32 ? 8 : nch <= 64 ? 16 : nch <= 128 ? 32 : 64;
-  const int grid = min(cdiv(rows, 4 * (64 / lanes)), 1024);
+  static const int grid_cap = [] { const char* v = getenv("SWG_LNB_GRID"); return v ? atoi(v) : 512; }();  // 2 per CU: more only adds column-sum atomics (1024: +0.2 ms per step)
+  const int grid = min(cdiv(rows, 4 * (64 / lanes)), grid_cap);
   const size_t lds = (size_t)2 * C * sizeof(float);
   SwgProfScope ps(KID_BWD_ROWS, 0.0, (double)rows * C * (dres ? 16.0 : 12.0), s);
 #define LNB(LN, VV) \
@@ -727,7 +728,8 @@ int launch_ln_cond_bwd(const float* x, const float* dxn, const float* dres, cons
   if (B <= 0 || L <= 0) return 0;
   if (!ln_cond_bwd_supported(C)) return SWG_E_UNSUPPORTED;
   if (!x || !dxn || !dres || !g || !cond || !dx || !dg || !db || !dcond) return SWG_E_NULL;
-  const int chunks = max(1, min(cdiv(L, 32), cdiv(4096, B)));  // ~4096 workgroups, at least 32 rows each
+  static const int wg_target = [] { const char* v = getenv("SWG_LCB_WGS"); return v ? atoi(v) : 1024; }();  // 4096: +0.17 ms per step
+  const int chunks = max(1, min(cdiv(L, 32), cdiv(wg_target, B)));  // ~wg_target workgroups, at least 32 rows each
   const int tpb = cdiv(L, chunks);
   const dim3 grid(cdiv(L, tpb), B);
   const size_t lds = (size_t)4 * C * sizeof(float);
