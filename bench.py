@@ -12,7 +12,14 @@ Extra objects in the JSON line:
   roofline     - dominant kernel of the run, timed live with HIP events by the library's profiler
                  (swg_prof_*) over a short profiled replay of the same workload after the timed region
   cpu_baseline - the CPU oracle (torch fp32, `oracle/`, kind "port") timed on this box's host cores on a
-                 bounded sample (few Heun steps, batch 1), extrapolated linearly in steps
+                 bounded sample (few Heun steps, batch 1), extrapolated linearly in steps; at two thread counts
+                 (`value` = the better one, both listed under `thread_counts`) plus the ego-small dim-60 case
+                 (BASELINE.json configs[0]) as a FULL 256-step sample
+  window_attn  - fused window-attention kernels against the bf16 MFMA peak, from the serial one-stream replay and
+                 (`two_stream_product_replay`) from a replay launched exactly as the timed region launches
+  train_step   - NOT the headline: one full train step (objective, forward, loss, backward, clip + Adam + 5 EMA) of
+                 the grid and community-small dim-96 configs at batch 80, same barrier discipline
+  ranks        - N > 1: backend and world size as torch.distributed reports them, per-rank wall time and batch
 """
 import argparse
 import json
@@ -52,8 +59,71 @@ def build_model(cfg, dev):
     return S.Precond("edm", net, True).to(dev).eval()
 
 
+def cpu_thread_counts():
+    """The two thread counts of SURVEY 8d (one socket's physical cores, all cores), clipped to what this process may
+    use: on the GPU box a job owns a 16-CPU share of a much larger machine (os.cpu_count() shows the whole machine),
+    so `all` = the share (torch's default thread count follows OMP_NUM_THREADS there) and `socket` = half of it."""
+    share = torch.get_num_threads()
+    try:
+        share = min(share, len(os.sched_getaffinity(0)))
+    except (AttributeError, OSError):
+        pass
+    share = max(share, 1)
+    return sorted({max(share // 2, 1), share})
+
+
 def cpu_baseline(cfg, state_dict, seconds_budget=20.0):
-    """Oracle (CPU port of the reference path) on a bounded sample: batch 1, few Heun steps."""
+    """Oracle (CPU port of the reference path) on a bounded sample, at two thread counts; `value` is the better."""
+    counts = cpu_thread_counts()
+    default_threads = torch.get_num_threads()
+    runs = []
+    try:
+        for k in counts:
+            torch.set_num_threads(k)
+            runs.append(_cpu_baseline_once(cfg, state_dict, seconds_budget / len(counts)))
+    finally:
+        torch.set_num_threads(default_threads)
+    best = max(runs, key=lambda r: r["value"])
+    out = dict(best)
+    out["thread_counts"] = [dict(cores=r["cores"], value=r["value"], sample=r["sample"]) for r in runs]
+    out["host"] = dict(os_cpu_count=os.cpu_count(), usable=counts[-1],
+                       note="os.cpu_count() is the whole machine; the job's CPU share is `usable`")
+    return out
+
+
+def cpu_ego_small_full(seconds_hint=10.0):
+    """BASELINE.json configs[0]: ego-small (<= 18 nodes) dim-60, a FULL 256-step EDM sample on the CPU oracle with
+    random-init weights (no extrapolation).  Batch sized for about `seconds_hint` seconds."""
+    from oracle import swingnn_ref as O
+    import swingnn_amd as S
+    cfg = CONFIGS["ego_small"]
+    ocfg = dict(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
+                depths=cfg["depths"], num_heads=[3, 6, 12, 24], window_size=cfg["window_size"], self_condition=True)
+    torch.manual_seed(1234)
+    net = S.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
+                    depths=cfg["depths"], num_heads=[3, 6, 12, 24], window_size=cfg["window_size"], mlp_ratio=4.,
+                    drop_rate=0., attn_drop_rate=0., drop_path_rate=0.0, self_condition=True)
+    sd = {k: v.detach().cpu() for k, v in S.Precond("edm", net, True).state_dict().items()}
+    den = lambda x, fl, sig, sc: O.precond_forward(sd, ocfg, x, fl, sig, np.random.rand() < 0.5)
+    torch.manual_seed(7)
+    np.random.seed(7)
+    with torch.no_grad():
+        f1 = make_flags(cfg, 1, np.random.default_rng(7))
+        t0 = time.perf_counter()
+        for _ in range(4):
+            den(O.gen_init_sample(f1) * 80.0, f1, torch.full((1,), 80.0), None)
+        per_call = (time.perf_counter() - t0) / 4
+        B = int(max(1, min(16, seconds_hint / max(per_call * 511.0, 1e-3))))
+        flags = make_flags(cfg, B, np.random.default_rng(8))
+        t0 = time.perf_counter()
+        out = O.edm_sample(den, flags, num_steps=256, self_condition=True)
+        dt = time.perf_counter() - t0
+    assert torch.isfinite(out).all()
+    return dict(value=B / dt, unit="graphs/s", cores=torch.get_num_threads(), kind="port",
+                sample=f"oracle edm_sample, ego-small dim-60, batch {B}, all 256 Heun steps in {dt:.1f} s")
+
+
+def _cpu_baseline_once(cfg, state_dict, seconds_budget):
     from oracle import swingnn_ref as O
     ocfg = dict(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
                 depths=cfg["depths"], num_heads=[3, 6, 12, 24], window_size=cfg["window_size"], self_condition=True)
@@ -90,10 +160,11 @@ def rank_env():
             int(os.environ.get("WORLD_SIZE", "1")))
 
 
-def timed_steps(step_fn, steps, warmup, sync, dist=None, device=None):
+def timed_steps(step_fn, steps, warmup, sync, dist=None, device=None, per_rank=None):
     """The driver's timing contract: `warmup` untimed steps, then EXACTLY `steps` steps bracketed by a barrier +
     device sync on both sides; returns the MAX over ranks of the wall time (seconds).  `sync` = device synchronise
-    (torch.cuda.synchronize on the GPU, a no-op in the CPU/gloo test)."""
+    (torch.cuda.synchronize on the GPU, a no-op in the CPU/gloo test).  `per_rank`: a list that receives every rank's
+    own wall time (time to its last step's end, before the closing barrier) in rank order."""
     def barrier():
         sync()
         if dist is not None:
@@ -106,12 +177,21 @@ def timed_steps(step_fn, steps, warmup, sync, dist=None, device=None):
     t0 = time.perf_counter()
     for _ in range(steps):
         step_fn()
+    sync()
+    own = time.perf_counter() - t0
     barrier()
     dt = time.perf_counter() - t0
     if dist is not None:
         t = torch.tensor([dt], dtype=torch.float64, device=device)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         dt = float(t.item())
+        if per_rank is not None:
+            mine = torch.tensor([own], dtype=torch.float64, device=device)
+            every = [torch.zeros_like(mine) for _ in range(dist.get_world_size())]
+            dist.all_gather(every, mine)
+            per_rank.extend(float(v.item()) for v in every)
+    elif per_rank is not None:
+        per_rank.append(own)
     return dt
 
 
@@ -159,6 +239,11 @@ def roofline_objects(kern, batch, config, launch_batch=None):
                                  GBs=round(v["bytes"] / (v["ms"] * 1e-3) / 1e9, 1)) for k, v in kern.items()},
                 sample="4-step sample() replay, same batch and the same (part-batch) launches, issued on one stream, "
                        "profiler on (untimed)")
+    return roof, window_attn_object(kern)
+
+
+def window_attn_object(kern):
+    """Fused window-attention kernel of every stage against the dense bf16 MFMA peak, from profiler tallies."""
     stages = {"s0_C96": "k_wattn_res", "s1_C192": "k_wattn_ring<192>", "s2_C384": "k_wattn_ring<384>",
               "s3_C768_core_only": "k_wattn_core"}
     wattn = {"peak_TFLOPs": MFMA_BF16_PEAK_TFLOPS,
@@ -176,7 +261,77 @@ def roofline_objects(kern, batch, config, launch_batch=None):
                 ms += v["ms"]
     if ms > 0:
         wattn["fused_kernels_mfma_util_pct"] = round(100.0 * fl / (ms * 1e-3) / 1e12 / MFMA_BF16_PEAK_TFLOPS, 2)
-    return roof, wattn
+    return wattn
+
+
+TRAIN_CONFIGS = {
+    # config/edm_swin_gnn/grid_edm_swin_gnn_80.yaml / com_small_edm_swin_gnn_80.yaml with --feature_dims 96, batch 80
+    "grid": dict(config="grid", batch=80),
+    "community_small": dict(config="community_small", batch=80),
+}
+
+
+def train_step_leg(name, dev, steps=10, warmup=3, sync=None, dist=None):
+    """One full train step (runner/trainer/trainer.py:108-140: objective -> Precond forward -> loss -> backward ->
+    clip_grad_norm_(10) + Adam + 5 EMA) timed with the bench's barrier discipline; then 2 profiled steps for the
+    dominant kernel and its roofline fraction.  Synthetic clean graphs (symmetric Bernoulli(0.3) in {-1, +1})."""
+    import swingnn_amd as S
+    from swingnn_amd import prof
+    tc = TRAIN_CONFIGS[name]
+    cfg, B = CONFIGS[tc["config"]], tc["batch"]
+    N = cfg["img_size"]
+    torch.manual_seed(1234)
+    np.random.seed(1234)
+    with torch.enable_grad():
+        net = S.SwinGNN(img_size=N, patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
+                        depths=cfg["depths"], num_heads=[3, 6, 12, 24], window_size=cfg["window_size"], mlp_ratio=4.,
+                        drop_rate=0., attn_drop_rate=0., drop_path_rate=0.0, self_condition=True)
+        model = S.Precond("edm", net, True).to(dev).train()
+        opt = S.FusedAdamEMA(model.parameters(), lr=1e-4, max_norm=10.0, ema_betas=(0.9, 0.95, 0.99, 0.999, 0.9999))
+        obj = S.EDMObjectiveGenerator("edm", "edm", dev=dev)
+        loss_fn = S.RainbowLoss(1.0, False, "edm")
+        flags = make_flags(cfg, B, np.random.default_rng(1234)).to(dev)
+        a = (torch.rand(B, N, N, device=dev) < 0.3).float() * 2 - 1
+        a = torch.triu(a, 1)
+        clean = (a + a.transpose(1, 2)) * flags[:, :, None] * flags[:, None, :]
+        last = {}
+
+        def step():
+            opt.zero_grad(set_to_none=True)
+            x, sig, tgt, (cs, co, ci, cn, sigmas, w) = obj.get_input_output(clean, flags)
+            D = model(x=x, node_flags=flags, sigmas=sig)
+            loss = loss_fn(D, tgt, sig, x, clean, flags, loss_weight=w, reduction='none').mean()
+            loss.backward()
+            opt.step()
+            last["loss"] = loss
+
+        sync = sync or torch.cuda.synchronize
+        dt = timed_steps(step, steps, warmup, sync, dist, dev)
+        with prof.profiled():
+            for _ in range(2):
+                step()
+            sync()
+            kern = prof.read()
+    loss = float(last["loss"].detach())
+    assert np.isfinite(loss)
+    total_ms = sum(k["ms"] for k in kern.values())
+    kname, dom = max(kern.items(), key=lambda kv: kv[1]["ms"])
+    avg_s = dom["ms"] * 1e-3 / dom["launches"]
+    tf = dom["flops"] / dom["launches"] / avg_s / 1e12
+    gbs = dom["bytes"] / dom["launches"] / avg_s / 1e9
+    bound = "mfma" if dom["flops"] / max(dom["bytes"], 1.0) >= MFMA_BF16_PEAK_TFLOPS * 1e12 / (HBM_PEAK_GBS * 1e9) else "hbm"
+    return dict(workload=f"{name} dim-{cfg['embed_dim']} N={N} train step, batch {B}: objective + forward + loss + backward + "
+                         "clip(10) + Adam + 5 EMA, random-init weights, synthetic graphs",
+                ms_per_step=dt / steps * 1e3, graphs_per_s=B * steps / dt, steps=steps, warmup=warmup, loss=loss,
+                params_M=round(sum(p.numel() for p in model.parameters()) / 1e6, 2),
+                kernel_ms_per_step=total_ms / 2,
+                dominant_kernel=dict(kernel=kname, share_of_gpu_time=dom["ms"] / total_ms, avg_launch_us=avg_s * 1e6,
+                                     launches_per_step=dom["launches"] // 2, bound=bound,
+                                     achieved=tf if bound == "mfma" else gbs, unit="TFLOP/s" if bound == "mfma" else "GB/s",
+                                     frac=(tf / MFMA_BF16_PEAK_TFLOPS) if bound == "mfma" else (gbs / HBM_PEAK_GBS),
+                                     note="bwd_rows tallies every fp32 row kernel of the backward under one name"
+                                     if kname == "bwd_rows" else None),
+                top_kernels={k: round(v["ms"] / 2, 3) for k, v in sorted(kern.items(), key=lambda kv: -kv[1]["ms"])[:8]})
 
 
 def main():
@@ -189,6 +344,7 @@ def main():
     ap.add_argument("--config", default="grid", choices=list(CONFIGS))
     ap.add_argument("--num-steps", type=int, default=256, help="Heun steps (256 = the shipped configs)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-train-step", action="store_true", help="skip the (non-headline) train-step legs")
     ap.add_argument("--no-pass-reuse", action="store_true", help="skip the extra (non-headline) run with reuse_passes")
     ap.add_argument("--graphs", type=int, default=0, choices=(0, 1),
                     help="1: EDMSampler.use_graphs (every network pass is one HIP-graph launch; same kernels, same bits)")
@@ -234,8 +390,10 @@ def main():
     def one_step():
         last["out"] = sampler.sample(model, flags)
 
+    per_rank = []
     with torch.no_grad():
-        dt = timed_steps(one_step, args.steps, args.warmup, torch.cuda.synchronize, dist if world > 1 else None, dev)
+        dt = timed_steps(one_step, args.steps, args.warmup, torch.cuda.synchronize, dist if world > 1 else None, dev,
+                         per_rank=per_rank)
     out = last["out"]
     assert torch.isfinite(out).all()
     from swingnn_amd import engine as _E
@@ -270,7 +428,16 @@ def main():
         with torch.no_grad(), prof.profiled():
             short.sample(model, flags)
         kern = prof.read()
-        roof, wattn = roofline_objects(kern, args.batch, args.config, _E.launch_batch(args.batch, cfg["img_size"]))
+        cache = _E.get_cache(model.model)
+        lb = _E.launch_batch(args.batch, cfg["img_size"], cache)
+        roof, wattn = roofline_objects(kern, args.batch, args.config, lb)
+        wattn["replay"] = "serial: part-batch launches one after the other on one stream (best case per launch)"
+        if lb != args.batch:
+            # the same replay launched as the timed region launches it: part-batches on two streams, each kernel's
+            # duration includes the time it shares the chip with the other part-batch's kernels
+            with torch.no_grad(), prof.profiled(serial=False):
+                short.sample(model, flags)
+            wattn["two_stream_product_replay"] = window_attn_object(prof.read())
         result = {
             "metric": json.load(open(os.path.join(ROOT, "BASELINE.json")))["metric"] if args.config == "grid"
             else f"sampled graphs/sec, EDM {args.config}",
@@ -280,12 +447,20 @@ def main():
             "config": {"workload": f"{args.config} EDM Heun sampling: N={cfg['img_size']}, nodes {cfg['n_nodes']}, "
                                    f"dim-{cfg['embed_dim']}, depths {cfg['depths']}, window {cfg['window_size']}, "
                                    f"{args.num_steps} steps, self_cond, random-init weights",
-                       "batch_per_gpu": args.batch, "global_batch": args.batch * world,
+                       "batch_per_gpu": args.batch, "global_batch": args.batch * world, "graphs_per_launch": lb,
                        "launch": "HIP-graph replay per network pass" if args.graphs else "eager kernel launches",
                        "parallelism": f"independent replicas x{world} (batch-sharded, no collective)"},
             "roofline": roof,
             "window_attn": wattn,
         }
+        result["ranks"] = dict(
+            world_size_env=world,
+            backend=(dist.get_backend() if world > 1 else None),
+            dist_world_size=(dist.get_world_size() if world > 1 else 1),
+            rccl=bool(world > 1 and not rehearsal),   # backend "nccl" IS RCCL on ROCm
+            per_rank_wall_s=[round(t, 4) for t in per_rank], max_over_ranks_wall_s=round(dt, 4),
+            per_rank_batch=args.batch, per_rank_seed="1234 + rank",
+            collectives_on_timed_path="none (barrier + one MAX all-reduce of the wall time outside the timed steps)")
         if rehearsal:
             result["rehearsal"] = f"{world} ranks sharing {torch.cuda.device_count()} GPU(s) over gloo: code-path check, not a scaling number"
         if reuse is not None:
@@ -293,6 +468,13 @@ def main():
         if not args.no_cpu_baseline and world == 1:  # the CPU leg is timed at N=1 only
             result["cpu_baseline"] = cpu_baseline(cfg, model.state_dict())
             result["gpu_over_cpu"] = result["value"] / result["cpu_baseline"]["value"]
+            if args.config == "grid":
+                result["cpu_baseline"]["ego_small_dim60_full_sample"] = cpu_ego_small_full()
+    # ---- extra, NOT the headline value: the train step of the two BASELINE configs that name one (N = 1 only) ----
+    if rank == 0 and world == 1 and not args.no_train_step and args.config == "grid":
+        del out, last
+        torch.cuda.empty_cache()
+        result["train_step"] = {name: train_step_leg(name, dev) for name in TRAIN_CONFIGS}
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()

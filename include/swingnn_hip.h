@@ -130,6 +130,12 @@ typedef struct swg_net {
 int swg_version(void);
 /* Bytes of scratch that swg_precond_forward / the op entry points need for batch B. */
 size_t swg_workspace_bytes(const swg_net* net, int32_t B);
+/* Number of ops of one pass over B graphs that take a batch-gated one-pass kernel (streamed MLP, projection + MLP
+ * tail, one-pass PatchMerging / PatchBreakup) instead of the GEMM route.  Host-side planning only (no launch): the
+ * caller that issues a pass as part-batches (swingnn_amd/engine.py network_pass; the reference's per-rank batch,
+ * runner/sampler/sampler_utils.py:254-258) compares the count of the part-batch with the count of the whole batch and
+ * does not split when the part-batch would fall below a gate.  <0: SWG_E_*. */
+int32_t swg_fused_op_count(const swg_net* net, int32_t B);
 
 /* ---- whole network pass -------------------------------------------------------------- *
  * mode 1: Precond.forward core, model/precond/precond.py:47-51 (edm branch of
@@ -263,6 +269,11 @@ int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, c
 int swg_edm_loss_noalloc(int32_t B, int32_t N, const float* pred, const float* target, const float* node_flags,
                          const float* weights, float regression_loss_weight, int32_t reduction_mean, float* loss,
                          void* stream);
+/* Set-up half of swg_edm_loss_noalloc (no counterpart in the reference either): resolves the address of the array on
+ * the CURRENT device (hipGetSymbolAddress, once per device; may load the code object).  Launches nothing.  Callers that
+ * will use swg_edm_loss_noalloc under stream capture call this once per device beforehand; otherwise the entry point's
+ * first call on a device does it. */
+int swg_edm_loss_noalloc_warmup(void);
 
 /* ---- training step: backward passes of the op-level entry points ------------------------ *
  * The reference has no explicit backward code: `loss.backward()` (runner/trainer/trainer.py:135) differentiates the

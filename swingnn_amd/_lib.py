@@ -104,6 +104,7 @@ _i32, _sz, _f = C.c_int32, C.c_size_t, C.c_float
 SYMBOLS = {
     "swg_version": (C.c_int, []),
     "swg_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),
+    "swg_fused_op_count": (_i32, [C.POINTER(SwgNet), _i32]),
     "swg_precond_forward": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
     "swg_noise_embed": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _sz, _fp]),
     "swg_patch_embed_fwd": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _i32, _fp, _i32, _fp, _fp]),
@@ -130,6 +131,7 @@ SYMBOLS = {
     "swg_edm_objective": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp, _fp]),
     "swg_edm_loss": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _f, _i32, _fp, _fp, _fp]),
     "swg_edm_loss_noalloc": (C.c_int, [_i32, _i32, _fp, _fp, _fp, _fp, _f, _i32, _fp, _fp]),
+    "swg_edm_loss_noalloc_warmup": (C.c_int, []),
     "swg_train_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),
     "swg_edm_coef": (C.c_int, [_i32, _fp, _i32, _i32, _fp, _fp, _fp]),
     "swg_wattn_bwd": (C.c_int, [C.POINTER(SwgBlock), C.POINTER(SwgBlockTrain), _i32, _fp, _fp, _i32, _fp, _fp, _fp, _i32,

@@ -106,10 +106,34 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
 // and the block carries the combined image, the projection, the shortcut and the whole MLP half run as ONE kernel
 // behind the attention core; otherwise the two halves run one after the other.  x_in == x_out is allowed.
 int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void* ws, size_t ws_bytes, hipStream_t s);
+// Token counts from which the one-pass kernels (one workgroup per CU streaming a whole weight) beat the GEMM route.
+// SWG_FUSED_MIN_TOKENS_PCT rescales all of them (tuning knob of scripts/, read once; 100 = the measured gates).
+static size_t fused_gate(size_t tokens) {
+  static const long pct = [] {
+    const char* e = getenv("SWG_FUSED_MIN_TOKENS_PCT");
+    const long v = e ? atol(e) : 100;
+    return v < 0 ? 100 : v;
+  }();
+  return tokens * (size_t)pct / 100;
+}
 bool fused_tail_ok(const swg_block* blk, int B) {
   const int C = blk->C, L = blk->res * blk->res;
-  return blk->proj_mlp_img && blk->attn_img && mlp_stream_proj_supported(C) && L % 32 == 0 && (size_t)B * L >= 16384 &&
-         wattn_ring_supported(C, blk->heads, blk->win, blk->res) && !wattn_ring_fuses_proj(C) && wattn_ring_wants_xn(C);
+  return blk->proj_mlp_img && blk->attn_img && mlp_stream_proj_supported(C) && L % 32 == 0 &&
+         (size_t)B * L >= fused_gate(16384) && wattn_ring_supported(C, blk->heads, blk->win, blk->res) &&
+         !wattn_ring_fuses_proj(C) && wattn_ring_wants_xn(C);
+}
+static bool mlp_stream_ok(const swg_block* blk, int B) {
+  const int C = blk->C;
+  const size_t T = (size_t)B * blk->res * blk->res;
+  return blk->mlp_img && !mlp_fused_supported(C) && mlp_stream_supported(C) && T >= fused_gate(C == 384 ? 16384 : 8192);
+}
+static bool merge_fused_ok(const swg_merge* m, int B) {
+  const size_t T4 = (size_t)B * (m->res / 2) * (m->res / 2);
+  return m->img && merge_fused_supported(m->C, m->res) && T4 >= fused_gate(16384);
+}
+static bool expand_fused_ok(const swg_breakup* u, int B) {
+  const size_t T = (size_t)B * u->res * u->res;
+  return u->img_pre && u->img_post && expand_fused_supported(u->Cin) && T >= fused_gate(16384);
 }
 int block_impl(const swg_block* blk, int B, const float* x_in, const float* cond, int cond_stride, float* x_out, void* ws,
                size_t ws_bytes, hipStream_t s) {
@@ -142,7 +166,7 @@ int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void*
                             blk->ln2.b, s);
   // the streamed kernel pays a fixed weight-stream latency per workgroup (~90 us at C = 384, ~35 us at C = 192): below
   // these token counts the three-kernel GEMM path is faster (measured: community-small, 4 / 16 tokens per graph)
-  if (blk->mlp_img && mlp_stream_supported(C) && T >= (C == 384 ? 16384 : 8192))
+  if (mlp_stream_ok(blk, B))
     return launch_mlp_stream(C, T, x_in, x_out, (const bf16*)blk->mlp_img, blk->fc1.b, blk->fc2.b, blk->ln2.g,
                              blk->ln2.b, s);
   Carver cv(ws, ws_bytes);
@@ -166,7 +190,8 @@ int merge_impl(const swg_merge* m, int B, const float* x_in, float* x_out, void*
   const int T4 = B * (m->res / 2) * (m->res / 2), Kp = kp(4 * m->C);
   // one pass for the narrow stages; a workgroup takes 128 merged tokens and streams the whole weight, so small token
   // counts stay on the GEMM
-  if (m->img && merge_fused_supported(m->C, m->res) && T4 >= 16384)
+  // (not in place: a workgroup's output rows [T4, 2C] overlap other workgroups' input rows)
+  if (merge_fused_ok(m, B) && (const float*)x_out != x_in)
     return launch_merge_fused(m->C, B, m->res, x_in, (const bf16*)m->img, m->ln.g, m->ln.b, x_out, s);
   Carver cv(ws, ws_bytes);
   bf16* xn = cv.take<bf16>((size_t)T4 * Kp);
@@ -188,7 +213,7 @@ int expand_impl(const swg_breakup* u, int B, const float* x, const float* skip, 
   // one pass over x and skip for the last decoder level; a workgroup takes 128 tokens and streams the whole
   // pre_linear weight, so small token counts stay on the GEMM
   // (not in place: a workgroup's output rows are other workgroups' input rows)
-  if (u->img_pre && u->img_post && expand_fused_supported(Cin) && T >= 16384 && x_out != x && x_out != skip)
+  if (expand_fused_ok(u, B) && x_out != x && x_out != skip)
     return launch_expand_fused(Cin, B, u->res, x, skip, (const bf16*)u->img_pre, (const bf16*)u->img_post, u->ln.g,
                                u->ln.b, u->post_ln.g, u->post_ln.b, x_out, s);
   Carver cv(ws, ws_bytes);
@@ -411,6 +436,22 @@ size_t swg_workspace_bytes(const swg_net* net, int32_t B) {
   NetPlan pl;
   if (B <= 0 || plan_net(net, B, &pl)) return 0;
   return pl.persistent + pl.scratch + 4096;
+}
+
+int32_t swg_fused_op_count(const swg_net* net, int32_t B) {
+  if (!net || !net->layers || B <= 0) return SWG_E_NULL;
+  int32_t n = 0;
+  for (int li = 0; li < net->n_layers; ++li) {
+    const swg_layer& ly = net->layers[li];
+    if (ly.up && expand_fused_ok(ly.up, B)) ++n;
+    for (int j = 0; j < ly.n_blocks; ++j) {
+      const swg_block* b = &ly.blocks[j];
+      if (fused_tail_ok(b, B)) n += 2;
+      else if (mlp_stream_ok(b, B)) ++n;
+    }
+    if (ly.down && merge_fused_ok(ly.down, B)) ++n;
+  }
+  return n;
 }
 
 int swg_linear_bf16(int32_t M, int32_t N, int32_t Kp, const void* a, int32_t lda, const void* w, const float* bias,

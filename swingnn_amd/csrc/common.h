@@ -39,6 +39,11 @@ static inline size_t align256(size_t v) { return (v + 255) & ~(size_t)255; }
 // byte counts go through this, never through an unqualified max(): in a .hip translation unit max(size_t, size_t) can
 // bind to the int overload and silently drops every term above 2^31 (a workspace plan that shrinks as the batch grows)
 static inline size_t smax(size_t a, size_t b) { return a > b ? a : b; }
+// every pointer 16-byte aligned (NULL counts as aligned): the gate of the float4 forms of the elementwise kernels
+template <class... P>
+static inline bool aligned16(const P*... p) {
+  return ((reinterpret_cast<uintptr_t>(p) | ...) & 15) == 0;
+}
 
 // x * sigmoid(x) with the hardware reciprocal and exponential (v_rcp_f32 / v_exp_f32, 1 ulp each).  NOT __frcp_rn:
 // hipcc lowers that to the correctly rounded division (v_div_scale x2, v_div_fmas, v_div_fixup, 4 fmas: ~12 VALU

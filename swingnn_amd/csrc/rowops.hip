@@ -793,7 +793,9 @@ int launch_sym_precond_ch(int B, int Ca, int N, const float* F, const float* x, 
                           float* out, float* sym_err, hipStream_t s) {
   SwgProfScope ps(KID_SYM_PRECOND, 0.0, 4.0 * B * Ca * (double)N * N * (x ? 3 : 2), s);
   const int nt = cdiv(N, 32);
-  if (N % 4 == 0) {
+  // the mirrored-tile form reads / writes float4: every operand must be 16-byte aligned (public entry points hand in
+  // arbitrary float* views)
+  if (N % 4 == 0 && aligned16(F, x, flags, out)) {
     hipLaunchKernelGGL(k_sym_precond_pair, dim3(nt * (nt + 1) / 2, 1, B * Ca), dim3(256), 0, s, N, Ca, nt, F, x, flags,
                        coef, out, sym_err);
   } else {
@@ -1085,7 +1087,7 @@ __global__ __launch_bounds__(1024) void k_edm_loss_sums(int N, const float* __re
 
 static void launch_edm_loss_sums(int B, int N, const float* pred, const float* target, const float* node_flags,
                                  const float* weights, float* S, float* nn, hipStream_t s) {
-  const bool vec = N % 4 == 0 && ((reinterpret_cast<uintptr_t>(pred) | reinterpret_cast<uintptr_t>(target)) & 15) == 0;
+  const bool vec = N % 4 == 0 && aligned16(pred, target);
   if (vec) hipLaunchKernelGGL(k_edm_loss_sums<true>, dim3(B), dim3(1024), 0, s, N, pred, target, node_flags, weights, S, nn);
   else hipLaunchKernelGGL(k_edm_loss_sums<false>, dim3(B), dim3(1024), 0, s, N, pred, target, node_flags, weights, S, nn);
 }
@@ -1093,9 +1095,16 @@ static void launch_edm_loss_sums(int B, int N, const float* pred, const float* t
 // reduction 'none': loss_b = S_b / n_b^2 * rlw ; reduction 'mean' (rainbow_loss.py:94-96): (sum_b S_b) / n_b^2 * rlw
 __global__ void k_edm_loss_finish(int B, const float* __restrict__ S, const float* __restrict__ nn, float rlw, int mean,
                                   float* __restrict__ loss) {
-  float tot = 0.f;
-  if (mean)
-    for (int b = 0; b < B; ++b) tot += S[b];
+  __shared__ float s_tot;
+  if (mean) {   // one thread sums in index order (the order is part of the result's bits), the others wait
+    if (threadIdx.x == 0) {
+      float tot = 0.f;
+      for (int b = 0; b < B; ++b) tot += S[b];
+      s_tot = tot;
+    }
+    __syncthreads();
+  }
+  const float tot = mean ? s_tot : 0.f;
   for (int b = threadIdx.x; b < B; b += blockDim.x) loss[b] = (mean ? tot : S[b]) / (nn[b] * nn[b]) * rlw;
 }
 
@@ -1118,7 +1127,7 @@ int swg_heun_euler(int32_t B, int32_t N, const float* x_hat, const float* denois
   if (B <= 0 || N <= 0 || t_hat == 0.f) return SWG_E_SHAPE;
   const size_t total = (size_t)B * N * N;
   SwgProfScope ps(KID_HEUN, 0.0, 16.0 * total, (hipStream_t)stream);
-  if (N % 4 == 0)
+  if (N % 4 == 0 && aligned16(x_hat, denoised, node_flags, d_cur, x_prime))
     hipLaunchKernelGGL(k_heun_euler4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
                        total / 4, x_hat, denoised, node_flags, 1.0f / t_hat, h, mask_out, d_cur, x_prime);
   else
@@ -1135,7 +1144,7 @@ int swg_heun_correct(int32_t B, int32_t N, const float* x_hat, const float* x_pr
   if (B <= 0 || N <= 0 || t_prime == 0.f) return SWG_E_SHAPE;
   const size_t total = (size_t)B * N * N;
   SwgProfScope ps(KID_HEUN, 0.0, 20.0 * total, (hipStream_t)stream);
-  if (N % 4 == 0)
+  if (N % 4 == 0 && aligned16(x_hat, x_prime, d_cur, denoised2, node_flags, x_next))
     hipLaunchKernelGGL(k_heun_correct4, dim3((unsigned)((total / 4 + 255) / 256)), dim3(256), 0, (hipStream_t)stream, N,
                        total / 4, x_hat, x_prime, d_cur, denoised2, node_flags, 1.0f / t_prime, h, x_next);
   else
@@ -1193,7 +1202,9 @@ int swg_edm_loss(int32_t B, int32_t N, const float* pred, const float* target, c
 // ---- swg_edm_loss_noalloc: the loss without a caller workspace (for callers that cannot allocate) ------------
 // The per-graph partial sums (S_b, n_b) of k_edm_loss_sums live in a file-scope device array instead of the
 // caller's scratch2B.  `scratch` below is the HOST-side stand-in of that array: host code only ever uses the
-// per-device address obtained once through hipGetSymbolAddress.
+// per-device address obtained once through hipGetSymbolAddress.  That first call per device may load the code object
+// lazily, so it must happen OUTSIDE a stream capture: swg_edm_loss_noalloc_warmup() (or any earlier call of the entry
+// point on that device) resolves it.
 #define SWG_LOSS_NOALLOC_MAX_B 65536
 static __device__ __align__(256) float scratch[2 * SWG_LOSS_NOALLOC_MAX_B];  // 512 KiB per GPU the library runs on
 
@@ -1221,6 +1232,11 @@ int loss_scratch_ptr(float** out) {
   return 0;
 }
 }  // namespace
+
+extern "C" int swg_edm_loss_noalloc_warmup(void) {
+  float* ptr = nullptr;
+  return loss_scratch_ptr(&ptr);
+}
 
 extern "C" int swg_edm_loss_noalloc(int32_t B, int32_t N, const float* pred, const float* target,
                                     const float* node_flags, const float* weights, float regression_loss_weight,

@@ -33,15 +33,24 @@ def stream_ptr():
 
 
 _WS = {}
+_WS_PRIVATE = None   # while graphed_pass records: {(device, stream): buffer owned by the graph entry}
 
 
 def workspace(device, nbytes: int) -> torch.Tensor:
     """Scratch buffer from torch's caching allocator, one per (device, stream): passes issued on different streams
     (a sampler on a side stream next to training, the two half-batch streams of network_pass) never share scratch.  A
-    buffer that is outgrown is handed back to the allocator only after the work queued on its stream (record_stream)."""
+    buffer that is outgrown is handed back to the allocator only after the work queued on its stream (record_stream).
+    While a HIP graph is being recorded the buffers come from the recording's own set instead (graphed_pass): a graph
+    bakes the scratch ADDRESS into its nodes, so that memory must live as long as the graph, not as long as the pool
+    entry."""
     idx = device.index if device.index is not None else torch.cuda.current_device()
     stream = torch.cuda.current_stream(idx)
     key = (idx, stream.cuda_stream)
+    if _WS_PRIVATE is not None:
+        buf = _WS_PRIVATE.get(key)
+        if buf is None or buf.numel() < nbytes:
+            raise RuntimeError("graph recording: no private workspace of the needed size for this stream")
+        return buf
     buf = _WS.get(key)
     if buf is None or buf.numel() < nbytes:
         if buf is not None:
@@ -491,6 +500,7 @@ class NetCache:
             C.cast(layers, C.POINTER(L.SwgLayer)), keep.ln(model.norm), _ptr(ro_w), ro_b)
         self.layers = layers
         self._ws_bytes = {}
+        self._fused_ops = {}
         self.table = RefreshTable(keep.registry, dev)
 
     def refresh(self, model):
@@ -512,6 +522,13 @@ class NetCache:
                 self._ro_w.copy_(ro_w)
                 self.net.ro_b = ro_b
         self.generation += 1
+
+    def fused_ops(self, B: int) -> int:
+        """Ops of a pass over B graphs that take a batch-gated one-pass kernel (swg_fused_op_count)."""
+        n = self._fused_ops.get(B)
+        if n is None:
+            n = self._fused_ops[B] = int(L.lib.swg_fused_op_count(C.byref(self.net), B))
+        return n
 
     def ws_bytes(self, B: int) -> int:
         n = self._ws_bytes.get(B)
@@ -574,10 +591,17 @@ _SIDE = {}
 _PROFILING = False           # set by prof.profiled()
 
 
-def launch_batch(B: int, N: int) -> int:
-    """Graphs per kernel launch of a pass over B graphs of N nodes (the part-batch when the pass is split)."""
+def launch_batch(B: int, N: int, cache=None) -> int:
+    """Graphs per kernel launch of a pass over B graphs of N nodes (the part-batch when the pass is split).  With the
+    NetCache given, a split that would push a stage below the token gate of a one-pass kernel (csrc/api.hip
+    fused_gate: e.g. grid B = 56 -> 2 x 28 graphs = 16128 tokens at C = 384, under the 16384 of the streamed MLP) is
+    refused: the part-batch must take the same kernels as the whole batch (swg_fused_op_count)."""
     parts = SPLIT_STREAMS
-    return B if (parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK) else B // parts
+    if parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK:
+        return B
+    if cache is not None and cache.fused_ops(B // parts) != cache.fused_ops(B):
+        return B
+    return B // parts
 
 
 def _side_streams(idx: int, n: int):
@@ -609,12 +633,11 @@ def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
         raise AssertionError(f"Input image size ({x.shape[-2]}*{N}) doesn't match model ({cache.net.N}*{cache.net.N}).")
     if out is None:
         out = torch.empty_like(x)
-    parts = SPLIT_STREAMS
-    if (parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK or
-            (torch.cuda.is_current_stream_capturing() and not _CAPTURE_SPLIT)):
+    h = launch_batch(B, N, cache)
+    if h == B or (torch.cuda.is_current_stream_capturing() and not _CAPTURE_SPLIT):
         _launch_pass(cache, B, mode, x, flags, labels, labels_uniform, sc, out, sym_err)
         return out
-    h = B // parts
+    parts = B // h
     if _PROFILING:
         for lo in range(0, B, h):
             hi = lo + h
@@ -653,7 +676,7 @@ def graphed_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
     Same kernels, same launch geometry, same order within a part-batch as the eager pass: results are bit-identical
     (tests/test_gpu_parity.py::test_graph_replayed_sampler_is_bit_identical).  Graphs live on the NetCache, i.e. they
     are dropped together with the weight images when the parameters are replaced."""
-    global PASS_COUNT, GRAPH_REPLAYS, _CAPTURE_SPLIT
+    global PASS_COUNT, GRAPH_REPLAYS, _CAPTURE_SPLIT, _WS_PRIVATE
     if x.dtype != torch.float32 or not x.is_contiguous() or _PROFILING or torch.cuda.is_current_stream_capturing():
         return network_pass(cache, mode, x, node_flags, labels, labels_uniform, self_cond, sym_err=sym_err)
     flags, labels = _as_f32(node_flags), _as_f32(labels)
@@ -666,23 +689,38 @@ def graphed_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_unifo
     ent = graphs.get(key)
     if ent is None:
         out = torch.empty_like(x)
-        # eager run first: sizes the per-stream workspaces and sets the kernels' LDS opt-ins outside the recording
+        # eager run first: sets the kernels' LDS opt-ins outside the recording
         network_pass(cache, mode, x, flags, labels, labels_uniform, sc, out=out, sym_err=None)
         cs = _capture_stream(x.device)
-        if launch_batch(x.shape[0], x.shape[-1]) == x.shape[0]:
-            with torch.cuda.stream(cs):   # an unsplit pass records on `cs`: its workspace comes from the ordinary pool
-                workspace(x.device, cache.ws_bytes(x.shape[0]))
+        # Scratch of the recorded kernels: buffers the graph entry keeps alive (the eager pool of workspace() replaces
+        # a buffer that a later, larger pass outgrows, which would leave the recorded addresses dangling).  Graphs
+        # recorded from one caller stream replay in that stream's order, so they share one set; different caller
+        # streams get different sets.  Allocated on the caller's stream: every replay joins back into it.
+        B_, N_ = x.shape[0], x.shape[-1]
+        dev_idx = x.device.index if x.device.index is not None else torch.cuda.current_device()
+        hb = launch_batch(B_, N_, cache)
+        rec_streams = [cs] if hb == B_ else _side_streams(dev_idx, B_ // hb)
+        pool = cache.__dict__.setdefault("_graph_ws", {})
+        caller = torch.cuda.current_stream(dev_idx).cuda_stream
+        private = {}
+        for st in rec_streams:
+            need = max(cache.ws_bytes(hb), 1 << 20)
+            buf = pool.get((caller, st.cuda_stream))
+            if buf is None or buf.numel() < need:
+                buf = pool[(caller, st.cuda_stream)] = torch.empty(need, dtype=torch.uint8, device=x.device)
+            private[(dev_idx, st.cuda_stream)] = buf
         graph = torch.cuda.CUDAGraph()
-        _CAPTURE_SPLIT = True
+        _CAPTURE_SPLIT, _WS_PRIVATE = True, private
         try:
             with torch.cuda.graph(graph, stream=cs):
                 network_pass(cache, mode, x, flags, labels, labels_uniform, sc, out=out, sym_err=sym_err)
         finally:
-            _CAPTURE_SPLIT = False
+            _CAPTURE_SPLIT, _WS_PRIVATE = False, None
         PASS_COUNT -= 1          # the recording launched nothing
         while len(graphs) >= GRAPH_SLOTS:
             graphs.pop(next(iter(graphs)))
-        ent = graphs[key] = (graph, out, (x, flags, labels, sc, sym_err))   # the recorded addresses stay allocated
+        # the recorded addresses (inputs, output, scratch) stay allocated for the life of the entry
+        ent = graphs[key] = (graph, out, (x, flags, labels, sc, sym_err), tuple(private.values()))
     ent[0].replay()
     PASS_COUNT += 1
     GRAPH_REPLAYS += 1

@@ -19,7 +19,11 @@ _ISO = 5.0                                   # diagonal of removed (isolated) no
 # Eigenvalues of a normalised Laplacian lie in [0, 2], and 2 itself is common (every bipartite component has it).  The
 # reference histograms LAPACK's values with range=(-1e-5, 2): a 2 that LAPACK returns as 2 + 4e-16 is silently dropped,
 # one returned as 2 is counted -- a rounding accident of the host solver.  Here values within SNAP of the range are
-# counted in the end bin, whatever the device solver's last bits are.
+# counted in the end bin, whatever the device solver's last bits are.  `snap=0.0` (argument of graph_histograms /
+# eval_adjs) gives numpy's exact rule instead: a value outside [lo, hi] by any amount is dropped, as
+# np.histogram(range=(-1e-5, 2)) does (evaluation/stats.py:133).  The two differ only for eigenvalues that the solver
+# returns within 1e-9 ABOVE 2 (or below -1e-5): with the default, a bipartite component's eigenvalue 2 is always
+# counted; with numpy's rule it is counted or not depending on the solver's last bit.
 SNAP = 1e-9
 
 
@@ -35,8 +39,9 @@ def _adj(a, dev=None):
     return a.contiguous()
 
 
-def graph_histograms(adjs):
-    """[B,N,N] -> (degree histogram [B,N], clustering histogram [B,100], spectral pmf [B,200]), fp64 on the device."""
+def graph_histograms(adjs, snap=SNAP):
+    """[B,N,N] -> (degree histogram [B,N], clustering histogram [B,100], spectral pmf [B,200]), fp64 on the device.
+    snap: tolerance of the spectral histogram's range ends (see SNAP; 0.0 = numpy's exact binning)."""
     a = _adj(adjs)
     B, N = a.shape[0], a.shape[1]
     f64 = dict(dtype=torch.float64, device=a.device)
@@ -47,7 +52,7 @@ def graph_histograms(adjs):
                                   _ISO, ws.data_ptr(), ws.numel(), stream_ptr()), "swg_graph_hists")
     eig = torch.linalg.eigvalsh(lap).contiguous()       # [B, N] ascending; removed nodes give exactly _ISO
     pmf = torch.empty((B, SPECTRAL_BINS), **f64)
-    L.check(L.lib.swg_hist_pmf(B, N, SPECTRAL_BINS, eig.data_ptr(), SPECTRAL_RANGE[0], SPECTRAL_RANGE[1], SNAP,
+    L.check(L.lib.swg_hist_pmf(B, N, SPECTRAL_BINS, eig.data_ptr(), SPECTRAL_RANGE[0], SPECTRAL_RANGE[1], float(snap),
                                pmf.data_ptr(), stream_ptr()), "swg_hist_pmf")
     return deg, clu, pmf
 
@@ -66,12 +71,13 @@ def mmd_gaussian_tv(x, y, sigma=1.0):
     return float(out.item())
 
 
-def eval_adjs(ref_adjs, pred_adjs, dev="cuda"):
+def eval_adjs(ref_adjs, pred_adjs, dev="cuda", snap=SNAP):
     """eval_torch_batch(ref, pred, methods=['degree', 'cluster', 'spectral']) of evaluation/stats.py:362-393 on
-    adjacency tensors (lists of equally sized matrices or [B,N,N] tensors; the two sets may differ in N)."""
+    adjacency tensors (lists of equally sized matrices or [B,N,N] tensors; the two sets may differ in N).
+    snap: see SNAP (0.0 = numpy's exact range rule for the spectral histogram)."""
     stack = lambda s: s if torch.is_tensor(s) else torch.stack([torch.as_tensor(g, dtype=torch.float32) for g in s])
-    r = graph_histograms(_adj(stack(ref_adjs), dev))
-    p = graph_histograms(_adj(stack(pred_adjs), dev))
+    r = graph_histograms(_adj(stack(ref_adjs), dev), snap)
+    p = graph_histograms(_adj(stack(pred_adjs), dev), snap)
     out = {"degree": mmd_gaussian_tv(r[0], p[0], 1.0),      # stats.py:63
            "cluster": mmd_gaussian_tv(r[1], p[1], 0.1),     # :119
            "spectral": mmd_gaussian_tv(r[2], p[2], 1.0)}    # :170

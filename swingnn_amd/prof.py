@@ -17,14 +17,16 @@ def read():
 
 
 @contextmanager
-def profiled():
-    """Per-kernel timing: the part-batches of a split pass are issued one after the other on ONE stream meanwhile
-    (engine.network_pass would otherwise overlap the kernels of two part-batches, and each would be timed against the
-    other); the launches themselves are those of the product path."""
+def profiled(serial=True):
+    """Per-kernel timing.  serial=True: the part-batches of a split pass are issued one after the other on ONE stream
+    meanwhile (engine.network_pass would otherwise overlap the kernels of two part-batches, and each would be timed
+    against the other); the launches themselves are those of the product path.  serial=False: the pass is launched
+    exactly as the product path launches it (part-batches on their own streams); a kernel's duration then includes
+    the time it shares the chip with the other part-batch's kernels -- what the timed region of bench.py sees."""
     from . import engine
     L.lib.swg_prof_reset()
     L.lib.swg_prof_enable(1)
-    engine._PROFILING = True
+    engine._PROFILING = bool(serial)
     try:
         yield
     finally:

@@ -25,7 +25,11 @@ def _worker(rank, world, port, q):
         calls.append(time.perf_counter())
         time.sleep(SLEEP[rank])
 
-    dt = bench.timed_steps(step, STEPS, WARMUP, lambda: None, dist, None)
+    per_rank = []
+    dt = bench.timed_steps(step, STEPS, WARMUP, lambda: None, dist, None, per_rank=per_rank)
+    # every rank's own wall time, in rank order, on every rank: the slow rank's is the maximum (and <= the reported one)
+    assert len(per_rank) == world and per_rank[1] > per_rank[0] and max(per_rank) <= dt
+    assert abs(per_rank[rank] - STEPS * SLEEP[rank]) < 0.3
     q.put((rank, dt, len(calls), bench.whole_job_value(BATCH, world, STEPS, dt)))
     dist.barrier()
     dist.destroy_process_group()
@@ -54,8 +58,10 @@ def test_two_rank_timing_is_max_over_ranks():
 def test_single_process_path_and_json_objects():
     import bench
     n = []
-    dt = bench.timed_steps(lambda: n.append(1), 4, 2, lambda: None)
-    assert len(n) == 6 and dt >= 0.0
+    own = []
+    dt = bench.timed_steps(lambda: n.append(1), 4, 2, lambda: None, per_rank=own)
+    assert len(n) == 6 and dt >= 0.0 and len(own) == 1 and own[0] <= dt
+    assert bench.cpu_thread_counts()[-1] >= 1
     assert bench.whole_job_value(112, 8, 2, 4.0) == 448.0
     kern = {
         "k_mlp_stream<384>": dict(ms=12.0, flops=6 * 152e9, bytes=6 * 0.2e9, launches=6),
