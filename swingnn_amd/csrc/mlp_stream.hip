@@ -83,7 +83,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
             smem0 + (buf_off) + ((i) * 4 + wave) * 1024)
   // the token rows are requested BEFORE the ring is primed: loads return in order, so rows issued behind two chunks
   // of LDS-DMA would wait for them (C = 384: 192 registers of raw rows do not fit beside the LayerNorm temporaries)
-  constexpr bool ROWS_FIRST = C <= 192;
+  constexpr bool ROWS_FIRST = C <= 192 && !PROJ;
   f32x4 xr[ROWS_FIRST ? 2 : 1][ROWS_FIRST ? KS : 1][2];
   if (ROWS_FIRST) {
 #pragma unroll
@@ -367,7 +367,7 @@ int launch_mlp_stream(int C, int T, const float* x, float* out, const bf16* img,
 // attention tail + MLP half in one kernel (PROJ form above).  x_in: the BLOCK input (the shortcut is recomputed from
 // it), o: attention output [T, ldo] bf16, img: projection fragments followed by the mlp_stream image.  x_in == out is
 // allowed (a wave reads only the rows it writes).
-bool mlp_stream_proj_supported(int C) { return C == 384; }
+bool mlp_stream_proj_supported(int C) { return C == 384 || C == 192; }
 int launch_mlp_stream_proj(int C, int T, int L, const float* x_in, const bf16* o, int ldo, const float* cond, int cond_stride,
                            int cond_off, const float* proj_b, float* out, const bf16* img, const float* b1,
                            const float* b2, const float* g, const float* b, hipStream_t s) {
@@ -376,8 +376,9 @@ int launch_mlp_stream_proj(int C, int T, int L, const float* x_in, const bf16* o
   if (L <= 0 || L % 32 || T % L || ldo < C || ldo % 8) return SWG_E_SHAPE;  // a wave's 32 tokens lie in one graph
   if (!x_in || !o || !cond || !proj_b || !out || !img) return SWG_E_NULL;
   MlpArgs a = {x_in, out, img, b1, b2, g, b, T, o, ldo, proj_b, cond, cond_stride, cond_off, L};
-  SwgProfScope ps(KID_MLP_PROJ_384, 18.0 * T * (double)C * C, 10.0 * T * (double)C + 18.0 * C * C, s);
-  int rc = launch_one<384, 32, 3, 1, true>(a, s);
+  SwgProfScope ps(C == 384 ? KID_MLP_PROJ_384 : KID_MLP_PROJ_192, 18.0 * T * (double)C * C,
+                  10.0 * T * (double)C + 18.0 * C * C, s);
+  int rc = (C == 384) ? launch_one<384, 32, 3, 1, true>(a, s) : launch_one<192, 32, 3, 1, true>(a, s);
   if (rc) return rc;
   SWG_LAUNCH_CHECK();
   return 0;

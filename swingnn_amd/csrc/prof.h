@@ -38,6 +38,7 @@ enum SwgKernelId {
   KID_MLP_PROJ_384,
   KID_MERGE_FUSED,
   KID_EXPAND_FUSED,
+  KID_MLP_PROJ_192,
   KID_COUNT
 };
 

@@ -7,6 +7,17 @@
 // MFMA phases; at this width the kernel is bound by exactly those VALU phases and by the fp32 token stream.
 #include "common.h"
 
+// tuning switches (A/B builds of scripts/build_variant.sh).  Measured on one box, grid B = 112, us per pass (4 launches):
+// round-2 form 494; LayerNorm1 g / b from LDS 476 (default); + contiguous run of windows per wave 487; + the graph's
+// conditioning row staged in a per-wave LDS slot 588 (the staged row is re-read per token tile -- 36 instead of 12
+// reads -- and sits in the dependent chain of the SiLU; the global reads were hoisted out of the tile loop).
+#ifndef RES_WALK_CONTIG
+#define RES_WALK_CONTIG 0   // 1: every wave walks a contiguous run of windows; 0: windows dealt round-robin to the waves
+#endif
+#ifndef RES_COND_LDS
+#define RES_COND_LDS 0      // 1: (1 + scale | shift) of the wave's graph staged in LDS; 0: read through the address unit
+#endif
+
 namespace {
 
 struct ResAttnArgs {
@@ -45,6 +56,14 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
   // -3e38.  One conflict-free ds_read_b128 gives the initial accumulator of S^T = K Q^T: no per-score add, no index
   // tables in registers.
   f32x4* s_bias = reinterpret_cast<f32x4*>(s_pb + C);                 // [heads][NTM][NTM][64]
+  // LayerNorm1 weight / bias come from LDS (one broadcast ds_read_b128 per 4 channels) instead of through the address
+  // unit once per window: 12 of the 45 vector-memory reads of a window.  (RES_COND_LDS: also the conditioning row of
+  // the wave's graph as (1 + scale | shift), in a per-wave slot: measured slower, off.)
+  float* s_lng = reinterpret_cast<float*>(s_bias + a.heads * NTM * NTM * 64);   // [C]
+  float* s_lnb = s_lng + C;                                                   // [C]
+#if RES_COND_LDS
+  float* s_cond = s_lnb + C + (threadIdx.x >> 6) * (2 * C);                   // [NW][2C], this wave's slot
+#endif
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -62,7 +81,11 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
     for (int pc = wave; pc < npieces; pc += NW) lds_dma16(img_lane + (size_t)pc * 1024, smem0 + pc * 1024);
   }
   for (int i = tid; i < 3 * C; i += 64 * NW) s_qkvb[i] = a.qkv_b[i] * (i < C ? QSCALE : 1.0f);
-  for (int i = tid; i < C; i += 64 * NW) s_pb[i] = a.proj_b[i];
+  for (int i = tid; i < C; i += 64 * NW) {
+    s_pb[i] = a.proj_b[i];
+    s_lng[i] = a.ln_g[i];
+    s_lnb[i] = a.ln_b[i];
+  }
   for (int e = tid; e < a.heads * NTM * NTM * 64; e += 64 * NW) {
     const int ln = e & 63, t = e >> 6;
     const int qt = t % NTM, kt = (t / NTM) % NTM, hh = t / (NTM * NTM);
@@ -99,9 +122,18 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
     iyx[mt] = iy | (ix << 8);
   }
 
-  for (int wi_g = blockIdx.x * NW + wave; wi_g < total; wi_g += gridDim.x * NW) {
+  // every wave walks a CONTIGUOUS run of windows (mostly one graph: its conditioning row is staged once per run)
+  const int nwaves = gridDim.x * NW, gw = blockIdx.x * NW + wave;
+#if RES_WALK_CONTIG
+  const int per = total / nwaves, rem = total - per * nwaves;
+  const int w_lo = gw * per + min(gw, rem), w_hi = w_lo + per + (gw < rem ? 1 : 0), w_step = 1;
+#else
+  const int w_lo = gw, w_hi = total, w_step = nwaves;
+#endif
+  int b_cached = -1;
+  for (int wi_g = w_lo; wi_g < w_hi; wi_g += w_step) {
 #ifdef SWG_STAMPS
-    const int witer = (wi_g - (blockIdx.x * NW + wave)) / (gridDim.x * NW);
+    const int witer = (wi_g - w_lo) / w_step;
     const bool dbg = (witer == 3) && (blockIdx.x == 0 || blockIdx.x == 131) && (wave == 0 || wave == 5);
     const int dbgslot = (blockIdx.x == 0 ? 0 : 2) + (wave == 0 ? 0 : 1);
 #endif
@@ -125,7 +157,20 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
     // channel 32ks + 8lg + 4hh + r (rho order of the image rows), i.e. exactly the channels this lane conditions
     // below for k-step ks, so the epilogue is a plain store (no second pass over x, no second SiLU).
     f32x4 acc[NT][NTM];
-    const float* crow = a.cond + (size_t)b * a.cond_stride + a.cond_off;
+#if RES_COND_LDS
+    if (b != b_cached) {   // wave-uniform: stage (1 + scale | shift) of graph b in the wave's LDS slot
+      const float* crow = a.cond + (size_t)b * a.cond_stride + a.cond_off;
+      for (int i = lane; i < 2 * C; i += 64) s_cond[i] = crow[i] + (i < C ? 1.0f : 0.0f);
+      b_cached = b;
+      asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");   // own wave only: no barrier needed
+    }
+    const float* cnd = s_cond;
+    constexpr float ONE = 0.0f;
+#else
+    const float* cnd = a.cond + (size_t)b * a.cond_stride + a.cond_off;
+    constexpr float ONE = 1.0f;
+    (void)b_cached;
+#endif
 #pragma unroll
     for (int mt = 0; mt < NTM; ++mt) {
       const float* row = a.x + (size_t)tokq[mt] * C;
@@ -136,10 +181,10 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
         const int c0 = 32 * ks + 8 * lg;
         const float4 p0 = *reinterpret_cast<const float4*>(row + c0);
         const float4 p1 = *reinterpret_cast<const float4*>(row + c0 + 4);
-        const float4 sc0 = *reinterpret_cast<const float4*>(crow + c0);
-        const float4 sc1 = *reinterpret_cast<const float4*>(crow + c0 + 4);
-        const float4 sh0 = *reinterpret_cast<const float4*>(crow + C + c0);
-        const float4 sh1 = *reinterpret_cast<const float4*>(crow + C + c0 + 4);
+        const float4 sc0 = *reinterpret_cast<const float4*>(cnd + c0);        // 1 + scale (scale when read from memory)
+        const float4 sc1 = *reinterpret_cast<const float4*>(cnd + c0 + 4);
+        const float4 sh0 = *reinterpret_cast<const float4*>(cnd + C + c0);
+        const float4 sh1 = *reinterpret_cast<const float4*>(cnd + C + c0 + 4);
         const float xv[8] = {p0.x, p0.y, p0.z, p0.w, p1.x, p1.y, p1.z, p1.w};
         const float sc[8] = {sc0.x, sc0.y, sc0.z, sc0.w, sc1.x, sc1.y, sc1.z, sc1.w};
         const float sh[8] = {sh0.x, sh0.y, sh0.z, sh0.w, sh1.x, sh1.y, sh1.z, sh1.w};
@@ -148,7 +193,7 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
         const float pb[8] = {pb0.x, pb0.y, pb0.z, pb0.w, pb1.x, pb1.y, pb1.z, pb1.w};
 #pragma unroll
         for (int j = 0; j < 8; ++j) {
-          const float v = silu_f(sh[j] + xv[j] * (sc[j] + 1.f));
+          const float v = silu_f(fmaf(xv[j], sc[j] + ONE, sh[j]));
           x1[ks][j] = v;
           s += v;
           acc[2 * ks + (j >> 2)][mt][j & 3] = v + pb[j];
@@ -166,10 +211,10 @@ __global__ __launch_bounds__(64 * NW) void k_wattn_res(ResAttnArgs a) {
 #pragma unroll
       for (int ks = 0; ks < KS; ++ks) {
         const int c0 = 32 * ks + 8 * lg;
-        const float4 g0 = *reinterpret_cast<const float4*>(a.ln_g + c0);
-        const float4 g1 = *reinterpret_cast<const float4*>(a.ln_g + c0 + 4);
-        const float4 b0 = *reinterpret_cast<const float4*>(a.ln_b + c0);
-        const float4 b1 = *reinterpret_cast<const float4*>(a.ln_b + c0 + 4);
+        const float4 g0 = *reinterpret_cast<const float4*>(s_lng + c0);
+        const float4 g1 = *reinterpret_cast<const float4*>(s_lng + c0 + 4);
+        const float4 b0 = *reinterpret_cast<const float4*>(s_lnb + c0);
+        const float4 b1 = *reinterpret_cast<const float4*>(s_lnb + c0 + 4);
         const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
         const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
         bf16x8 f;
@@ -391,7 +436,8 @@ template <int WIN>
 int launch_res_t(const ResAttnArgs& a, int total, hipStream_t s) {
   constexpr int C = 96, NW = 8, AHEAD = 3, NTM = (WIN * WIN + 15) / 16;
   const size_t lds = (size_t)a.heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 + (size_t)(4 * C) * sizeof(float) +
-                     (size_t)a.heads * NTM * NTM * 1024;  // weights + read-ahead slack + biases + bias tiles
+                     (size_t)a.heads * NTM * NTM * 1024 +   // weights + read-ahead slack + biases + bias tiles
+                     (size_t)(2 * C + NW * 2 * C) * sizeof(float);  // LayerNorm1 g / b + per-wave conditioning rows
   const int nwg = min(cdiv(total, NW), 256);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
   if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_res<C, NW, AHEAD, WIN>, (int)((int)lds))) return e;

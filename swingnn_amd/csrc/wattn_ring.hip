@@ -48,6 +48,8 @@ __device__ __forceinline__ void wait_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
 }
 
+__host__ __device__ constexpr int ring_unit(int frags_head) { return frags_head % 24 == 0 ? 24 : frags_head; }
+
 template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN>
 __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   // window geometry: NTOK tokens in NTM 16-token MFMA tiles, KSP 32-deep k-steps over the keys; the last tile holds
@@ -59,13 +61,15 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   constexpr int SLAB = 2 * KS;                       // fragments per slab (== NT)
   constexpr int NSLAB = FUSE_PROJ ? 4 : 3;           // V, Q, K [, P]
   constexpr int FRAGS_HEAD = NSLAB * SLAB;
-  constexpr int UNIT = 24;                           // fragments per ring unit (one barrier per unit)
+  // fragments per ring unit (one barrier per unit): 24, or the whole head where 24 does not divide it (C = 192
+  // without the projection slab: 36)
+  constexpr int UNIT = ring_unit(FRAGS_HEAD);
   constexpr int UNIT_BYTES = UNIT * 1024;
   constexpr int UH = FRAGS_HEAD / UNIT;              // units per head
   constexpr int RING_BYTES = NBUF * UNIT_BYTES;
   constexpr int PIECES = UNIT / 4;                   // LDS-DMA pieces per wave per unit
   constexpr int DMA_EVERY = UNIT / PIECES;
-  static_assert(FRAGS_HEAD % UNIT == 0 && NBUF >= 3 && AHEAD < UNIT, "stream shape");
+  static_assert(FRAGS_HEAD % UNIT == 0 && UNIT % 4 == 0 && NBUF >= 3 && AHEAD < UNIT, "stream shape");
   static_assert(FRAGS_HEAD % (AHEAD + 1) == 0, "the register fragment ring must line up across heads");
   static_assert((NBUF - 2) * PIECES < 64, "vmcnt is 6 bits");
   constexpr int W2 = 2 * WIN - 1, NB = W2 * W2;
@@ -543,7 +547,8 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 
 template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN>
 int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
-  const size_t lds = (size_t)NBUF * 24 * 1024 + (size_t)(4 * C + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
+  constexpr int UNIT = ring_unit((FUSE_PROJ ? 4 : 3) * 2 * (C / 32));
+  const size_t lds = (size_t)NBUF * UNIT * 1024 + (size_t)(4 * C + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
   if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>, (int)((int)lds))) return e;
   hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>), dim3(nwg), dim3(256), lds, s, a);
@@ -555,7 +560,18 @@ int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
 bool wattn_ring_supported(int C, int heads, int win, int res) {
   return (C == 192 || C == 384) && heads * 32 == C && (win == 6 || win == 8) && res % win == 0;
 }
-bool wattn_ring_fuses_proj(int C) { return C != 384; }
+// C = 384: the projection accumulators do not fit beside the LN1 fragments.  C = 192: they fit, but the kernel runs
+// faster as the attention core alone (36 instead of 48 fragments per head, no 144 accumulator registers, no shortcut
+// epilogue) with the projection folded into the streamed MLP kernel (mlp_stream.hip PROJ form), as at C = 384.
+// SWG_RING192_FUSE_PROJ=1 restores the fused-projection form (A/B knob of scripts/; engine.py reads the same variable
+// when it builds the weight image).
+bool wattn_ring_fuses_proj(int C) {
+  static const bool fuse192 = [] {
+    const char* e = getenv("SWG_RING192_FUSE_PROJ");
+    return e && e[0] == '1';
+  }();
+  return C == 192 && fuse192;
+}
 
 bool wattn_ring_wants_xn(int C) { return true; }  // in-kernel LN (PRE_LN = false) measured slower at C = 192
 
@@ -581,10 +597,12 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
                   row_bytes * T * C + gemm * C * C, s);
   int r;
   if (blk->win == 8) {
-    if (C == 192) r = launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s);
+    if (C == 192) r = wattn_ring_fuses_proj(C) ? launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s)
+                                               : launch_t<192, false, 4, 1, 5, true, 8>(a, nwg, s);
     else r = launch_t<384, false, 5, 1, 5, true, 8>(a, nwg, s);
   } else {
-    if (C == 192) r = launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s);
+    if (C == 192) r = wattn_ring_fuses_proj(C) ? launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s)
+                                               : launch_t<192, false, 4, 1, 5, true, 6>(a, nwg, s);
     else r = launch_t<384, false, 5, 1, 5, true, 6>(a, nwg, s);
   }
   if (r) return r;

@@ -269,7 +269,11 @@ def proj_frag_image(proj_w: torch.Tensor, heads: int, dtype=torch.bfloat16) -> t
     return w.permute(2, 0, 3, 1, 4).reshape(-1).to(dtype).contiguous()             # [ks, nt, lg, i, e]
 
 
-PROJ_MLP_DIMS = (384,)   # channel counts with the fused attention-tail + MLP kernel (csrc/mlp_stream.hip, PROJ form)
+# csrc/wattn_ring.hip at C = 192 with the projection fused (round-2 form) instead of folded into the MLP kernel: A/B knob,
+# read by the library too (wattn_ring_fuses_proj)
+RING192_FUSE_PROJ = os.environ.get("SWG_RING192_FUSE_PROJ", "0") == "1"
+# channel counts with the fused attention-tail + MLP kernel (csrc/mlp_stream.hip, PROJ form)
+PROJ_MLP_DIMS = (384,) if RING192_FUSE_PROJ else (384, 192)
 USE_FUSED_ATTN = True
 
 
@@ -290,7 +294,7 @@ def _pi(device) -> torch.Tensor:
     return torch.where(e < 4, 4 * ch + e, 16 + 4 * ch + e - 4).reshape(-1)
 
 
-RING_ATTN_FUSED_PROJ = {96: True, 192: True, 384: False}  # 96: wattn_res.hip (weights resident in LDS)  # csrc/wattn_ring.hip geometries
+RING_ATTN_FUSED_PROJ = {96: True, 192: RING192_FUSE_PROJ, 384: False}  # 96: wattn_res.hip (weights resident in LDS)  # csrc/wattn_ring.hip geometries
 
 
 def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse_proj: bool,

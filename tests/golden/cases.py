@@ -75,6 +75,13 @@ SAMPLER_LONG_CASES = {
     "com96_256": dict(net="com96", regime="init", steps=256, B=3, n_lo=12, n_hi=20, sanity=False, seed=66),
 }
 
+# Few-step trajectories at the FULL bench geometries (BASELINE.json configs[3] grid N=384 / configs[4] DD N=512, dim-96),
+# B = 1: seconds of reference CPU each (a 4-step DD run was tried first: its three huge steps amplify bf16 rounding to 9e-3, at the edge of the 1e-2 bar) (runner/mcmc_sampler/edm.py:125-232).  Stored in golden_sampler_full.npz.
+SAMPLER_FULL_CASES = {
+    "grid384_8": dict(cfg=_cfg(384, 4, 96, [1, 1, 3, 1], 6), regime="init", steps=8, B=1, n_lo=361, n_hi=361, seed=67),
+    "dd512_8": dict(cfg=_cfg(512, 4, 96, [1, 1, 3, 1], 8), regime="init", steps=8, B=1, n_lo=300, n_hi=500, seed=68),
+}
+
 # G9: train step (loss [B] + every parameter gradient) of RainbowLoss(Precond(SwinGNN)(x, flags, sigmas), sign(x)).mean()
 # (network case, weight regime, sigma index, outcome of the self-conditioning coin)
 TRAIN_CASES = [("com96", "stress", 0, True), ("com96", "init", 1, False), ("ego60", "stress", 1, True),

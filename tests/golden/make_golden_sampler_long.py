@@ -7,6 +7,10 @@ Run in the build container only (needs /root/reference; the GPU box has none):
 
 Committed: golden_sampler_long.npz (final samples, thresholded samples, a few interim states).  Weights, flags and noise
 are regenerated on both sides from (name, shape, seed) / the seeded CPU generator.
+
+`--only full` / `--only long` restricts the run.  The `full` set (SAMPLER_FULL_CASES -> golden_sampler_full.npz) holds
+few-step trajectories at the FULL bench geometries (grid N=384 and DD N=512: 8 Heun steps, B = 1; final sample
+and thresholded sample only).
 """
 import os
 import sys
@@ -44,12 +48,16 @@ from runner.mcmc_sampler.edm import EDMSampler as REDMSampler  # noqa: E402
 from utils.attribute_code import attribute_converter as r_attribute_converter  # noqa: E402
 
 from oracle import filler  # noqa: E402
-from tests.golden.cases import NET_CASES, SAMPLER_LONG_CASES  # noqa: E402
+from tests.golden.cases import NET_CASES, SAMPLER_FULL_CASES, SAMPLER_LONG_CASES  # noqa: E402
 
 torch.set_grad_enabled(False)
-OUT = {}
-for name, c in SAMPLER_LONG_CASES.items():
-    cfg = NET_CASES[c["net"]]["cfg"]
+ONLY = sys.argv[sys.argv.index("--only") + 1] if "--only" in sys.argv else "both"
+OUT, FULL = {}, {}
+for name, c in list(SAMPLER_LONG_CASES.items()) + list(SAMPLER_FULL_CASES.items()):
+    full = name in SAMPLER_FULL_CASES
+    if (full and ONLY == "long") or (not full and ONLY == "full"):
+        continue
+    cfg = c["cfg"] if full else NET_CASES[c["net"]]["cfg"]
     net = R.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=cfg["in_chans"],
                     embed_dim=cfg["embed_dim"], depths=cfg["depths"], num_heads=cfg["num_heads"],
                     window_size=cfg["window_size"], mlp_ratio=4., drop_rate=0., attn_drop_rate=0.,
@@ -63,13 +71,17 @@ for name, c in SAMPLER_LONG_CASES.items():
     torch.manual_seed(c["seed"])
     np.random.seed(c["seed"])
     final, interim = smp.sample(pre, flags, flag_interim_adjs=True, max_num_interim_adjs=5)
-    OUT[f"sampler/{name}/final"] = final.numpy()
-    OUT[f"sampler/{name}/interim"] = interim.numpy()
+    dst = FULL if full else OUT
+    dst[f"sampler/{name}/final"] = final.numpy()
+    if not full:
+        dst[f"sampler/{name}/interim"] = interim.numpy()
     q = r_attribute_converter(in_attr=final.clamp(min=-1.0, max=1.0), attr_flags=flags, in_encoding="ddpm",
                               out_encoding="int", num_attr_type=2, flag_nodes=True, flag_adjs=False,
                               flag_in_ddpm_range=True, flag_out_ddpm_range=False)
-    OUT[f"sampler/{name}/thresholded"] = q.numpy().astype(np.float32)
+    dst[f"sampler/{name}/thresholded"] = q.numpy().astype(np.uint8 if full else np.float32)
     print(name, "done", flush=True)
 
-np.savez_compressed(os.path.join(HERE, "golden_sampler_long.npz"), **OUT)
-print("wrote", len(OUT), "arrays;", sum(v.nbytes for v in OUT.values()) / 1e6, "MB raw")
+for fname, arrays in (("golden_sampler_long.npz", OUT), ("golden_sampler_full.npz", FULL)):
+    if arrays:
+        np.savez_compressed(os.path.join(HERE, fname), **arrays)
+        print("wrote", fname, len(arrays), "arrays;", sum(v.nbytes for v in arrays.values()) / 1e6, "MB raw")

@@ -17,7 +17,7 @@ import torch
 from oracle import filler
 from oracle import swingnn_ref as O
 from tests import helpers as H
-from tests.golden.cases import HEADS, NET_CASES, SAMPLER_LONG_CASES
+from tests.golden.cases import HEADS, NET_CASES, SAMPLER_FULL_CASES, SAMPLER_LONG_CASES
 from tests.test_gpu_parity import DEV, load, rel_close, strip
 
 pytestmark = pytest.mark.gpu
@@ -343,6 +343,40 @@ def test_sampler_256_steps(golden_long, golden_meta, name):
     raw = float((thr == thr_ref)[valid].float().mean())
     sure = valid & (ref.abs() > 1e-2)
     filt = float((thr == thr_ref)[sure].float().mean())
+    print(f"{name}: final max err {err:.3g}, thresholded agreement raw {raw:.5f} filtered {filt:.5f}")
+    assert err <= 1e-2, err
+    assert filt >= 0.999 and raw >= 0.999, (raw, filt)
+
+
+@pytest.mark.parametrize("name", list(SAMPLER_FULL_CASES))
+def test_sampler_full_geometry(name):
+    """EDMSampler.sample at the EXACT bench geometries (grid N=384 and DD N=512: 8 Heun steps, B = 1) against the
+    reference's own trajectory (golden_sampler_full.npz, made by tests/golden/make_golden_sampler_long.py --only full
+    from runner/mcmc_sampler/edm.py:125-232 with the same seeded CPU draws)."""
+    import swingnn_amd as S
+    c = SAMPLER_FULL_CASES[name]
+    cfg = c["cfg"]
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_sampler_full.npz"), allow_pickle=False) as z:
+        ref, thr_ref = torch.from_numpy(z[f"sampler/{name}/final"]), torch.from_numpy(z[f"sampler/{name}/thresholded"])
+    net = S.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
+                    depths=cfg["depths"], num_heads=cfg["num_heads"], window_size=cfg["window_size"], mlp_ratio=4.,
+                    drop_rate=0., attn_drop_rate=0., drop_path_rate=0.0, self_condition=True)
+    pre = S.Precond("edm", net, True)
+    pre.load_state_dict(filler.fill_state_dict(pre.state_dict(), c["seed"], c["regime"]))
+    pre = pre.to(DEV).eval()
+    smp = S.EDMSampler(num_steps=c["steps"], clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
+                       clip_samples_scope="x_0", self_condition=True, dev=DEV)
+    flags = filler.node_flags("flags", c["B"], cfg["img_size"], c["n_lo"], c["n_hi"], c["seed"])
+    torch.manual_seed(c["seed"])
+    np.random.seed(c["seed"])
+    smp._randn_like = lambda x: torch.randn(x.shape).to(x.device)   # the reference drew from the CPU generator
+    final = smp.sample(pre, flags.to(DEV))
+    err = float((final - ref).abs().max())
+    thr = O.threshold_adj(final, flags)
+    valid = (flags[:, :, None] * flags[:, None, :]) > 0
+    raw = float((thr == thr_ref.float())[valid].float().mean())
+    sure = valid & (ref.abs() > 1e-2)
+    filt = float((thr == thr_ref.float())[sure].float().mean())
     print(f"{name}: final max err {err:.3g}, thresholded agreement raw {raw:.5f} filtered {filt:.5f}")
     assert err <= 1e-2, err
     assert filt >= 0.999 and raw >= 0.999, (raw, filt)

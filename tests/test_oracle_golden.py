@@ -138,6 +138,31 @@ def test_edm_sampler_long_com96(golden_meta):
     assert float((O.threshold_adj(out, flags) == thr_ref).float().mean()) >= 0.999
 
 
+def test_edm_sampler_full_geometry_grid384():
+    """The oracle replays the reference's 8-step EDMSampler.sample at the FULL grid geometry (N = 384, dim-96,
+    golden_sampler_full.npz from make_golden_sampler_long.py --only full): pins the oracle where bench.py runs."""
+    import os
+    from tests.golden.cases import SAMPLER_FULL_CASES
+    name = "grid384_8"
+    c = SAMPLER_FULL_CASES[name]
+    cfg = c["cfg"]
+    with np.load(os.path.join(os.path.dirname(__file__), "golden", "golden_sampler_full.npz"), allow_pickle=False) as z:
+        ref, thr_ref = torch.from_numpy(z[f"sampler/{name}/final"]), torch.from_numpy(z[f"sampler/{name}/thresholded"])
+    import swingnn_amd as S      # parameter containers only (same state_dict keys / shapes as the reference's modules)
+    net = S.SwinGNN(img_size=cfg["img_size"], patch_size=cfg["patch_size"], in_chans=1, embed_dim=cfg["embed_dim"],
+                    depths=cfg["depths"], num_heads=cfg["num_heads"], window_size=cfg["window_size"], mlp_ratio=4.,
+                    drop_rate=0., attn_drop_rate=0., drop_path_rate=0.0, self_condition=True)
+    sd = filler.fill_state_dict(S.Precond("edm", net, True).state_dict(), c["seed"], c["regime"])
+    flags = filler.node_flags("flags", c["B"], cfg["img_size"], c["n_lo"], c["n_hi"], c["seed"])
+    torch.manual_seed(c["seed"])
+    np.random.seed(c["seed"])
+    with torch.no_grad():
+        out = O.edm_sample(lambda x, fl, sig, sc: O.precond_forward(sd, cfg, x, fl, sig, np.random.rand() < 0.5), flags,
+                           num_steps=c["steps"], self_condition=True)
+    close(out, ref, 5e-5)
+    assert float((O.threshold_adj(out, flags) == thr_ref.float()).float().mean()) >= 0.9999
+
+
 def test_objective_and_loss(golden):
     B, N = 6, 24
     flags = filler.node_flags("flags", B, N, 5, 20, 3)
