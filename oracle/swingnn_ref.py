@@ -21,6 +21,47 @@ SIGMA_DATA = 0.5          # runner/objectives/edm.py:60-63
 NOISE_EMB = 512           # model/swin_gnn/swin_gnn.py:634
 MASK_NEG = -100.0         # model/swin_gnn/swin_gnn.py:226
 
+# --------------------------------------------------------------------------------------
+# bf16-operand mode (test infrastructure for the tolerance tests, NOT the reference's arithmetic)
+# --------------------------------------------------------------------------------------
+# The reference computes in fp32 throughout.  The HIP path rounds the OPERANDS of the token-wise matrix products to
+# bfloat16 (fp32 accumulate; everything else fp32).  With `bf16_operands()` active the oracle rounds the same
+# operands at the same places -- the inputs and weights of qkv / proj / fc1 / fc2 / PatchMerging.reduction /
+# PatchBreakup.pre_linear / post_linear, q (scaled, with bias), k, v, the unnormalised softmax numerators and the
+# attention output -- so that what is left between the two is accumulation order and the transcendental
+# approximations.  The parity tests then hold the unit-gain ('stress') regime to a bar ~20x tighter than against the
+# fp32 goldens, where the bar has to absorb the rounding itself.  Patch embedding, read-out, noise embedding and the
+# conditioning GEMV are fp32-grade in the HIP path and stay fp32 here.  Under autograd the casts round the incoming
+# gradients at the same points (the HIP backward feeds bf16 dY operands to its products too).
+_BF16 = False
+_BF16_Q = "auto"
+LOG2E = 1.4426950408889634
+
+
+class bf16_operands:
+    """Context manager: round matrix-product operands to bfloat16 like the HIP kernels do.  `q`: where the query is
+    rounded -- "log2" (fused window kernels: q * hd^-1/2 * log2 e), "raw" (GEMM route: the unscaled qkv row) or
+    "auto" (per block, by the geometry rule of csrc/api.hip: fused for head_dim 32, C in {96, 192, 384}, windows
+    4 / 6 / 8 at C = 96 and 6 / 8 above).  At
+    unit-gain weights the softmax is sharp enough that this choice alone moves a block's output by 3e-3 of its scale."""
+
+    def __init__(self, q="auto"):
+        self.q = q
+
+    def __enter__(self):
+        global _BF16, _BF16_Q
+        self._old, _BF16, _BF16_Q = (_BF16, _BF16_Q), True, self.q
+        return self
+
+    def __exit__(self, *exc):
+        global _BF16, _BF16_Q
+        _BF16, _BF16_Q = self._old
+        return False
+
+
+def _rb(t):
+    return t.to(torch.bfloat16).to(torch.float32) if _BF16 else t
+
 
 # --------------------------------------------------------------------------------------
 # geometry
@@ -99,6 +140,11 @@ def _lin(x, sd, pfx):
     return F.linear(x, sd[pfx + ".weight"], sd.get(pfx + ".bias"))
 
 
+def _lin_mm(x, sd, pfx):
+    """A Linear that the HIP path runs on MFMA: operands rounded in bf16-operand mode, bias added in fp32."""
+    return F.linear(_rb(x), _rb(sd[pfx + ".weight"]), sd.get(pfx + ".bias"))
+
+
 def _ln(x, sd, pfx):
     return F.layer_norm(x, (x.shape[-1],), sd[pfx + ".weight"], sd[pfx + ".bias"], 1e-5)
 
@@ -123,17 +169,35 @@ def window_attention(xw, sd, pfx, heads, w, mask):
     """xw [B_, n, C] -> [B_, n, C]; swin_gnn.py:108-139."""
     B_, n, C = xw.shape
     hd = C // heads
-    qkv = _lin(xw, sd, pfx + ".qkv").reshape(B_, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
-    q, k, v = qkv[0] * hd ** -0.5, qkv[1], qkv[2]
+    qkv = _lin_mm(xw, sd, pfx + ".qkv").reshape(B_, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
+    q_mode = _BF16_Q
+    if q_mode == "auto":   # which route the library takes for this geometry (csrc/api.hip wattn_impl)
+        fused = hd == 32 and C in (96, 192, 384) and w in ((4, 6, 8) if C == 96 else (6, 8))
+        q_mode = "log2" if fused else "raw"
+    if _BF16 and q_mode == "log2":
+        # the fused window kernels keep the scores in the log2 domain: q is rounded as q * hd^-1/2 * log2(e)
+        q = _rb(qkv[0] * (hd ** -0.5 * LOG2E)) / LOG2E
+    elif _BF16 and q_mode == "raw":
+        # the GEMM route (head_dim 20, C = 768, small windows) rounds the packed qkv rows as the GEMM wrote them and
+        # applies the scale to the fp32 scores
+        q = _rb(qkv[0]) * hd ** -0.5
+    else:
+        q = qkv[0] * hd ** -0.5
+    k, v = _rb(qkv[1]), _rb(qkv[2])
     att = q @ k.transpose(-2, -1)                                          # [B_, nH, n, n]
     bias = sd[pfx + ".relative_position_bias_table"][relative_position_index(w).reshape(-1)]
     att = att + bias.reshape(n, n, heads).permute(2, 0, 1)[None]
     if mask is not None:
         nW = mask.shape[0]
         att = (att.reshape(B_ // nW, nW, heads, n, n) + mask[None, :, None]).reshape(B_, heads, n, n)
-    att = att.softmax(dim=-1)
-    out = (att @ v).transpose(1, 2).reshape(B_, n, C)
-    return _lin(out, sd, pfx + ".proj")
+    if _BF16:   # the kernels round the UNNORMALISED numerators and divide the product by the fp32 row sum
+        e = (att - att.amax(dim=-1, keepdim=True)).exp()
+        out = (_rb(e) @ v) / e.sum(dim=-1, keepdim=True)
+    else:
+        att = att.softmax(dim=-1)
+        out = att @ v
+    out = out.transpose(1, 2).reshape(B_, n, C)
+    return _lin_mm(out, sd, pfx + ".proj")
 
 
 def swin_block(x, emb, sd, pfx, res, heads, window, shift):
@@ -152,8 +216,8 @@ def swin_block(x, emb, sd, pfx, res, heads, window, shift):
     if s > 0:
         y = torch.roll(y, shifts=(s, s), dims=(1, 2))
     x = short + y.reshape(B, L, C)
-    h = F.gelu(_lin(_ln(x, sd, pfx + ".norm2"), sd, pfx + ".mlp.fc1"))
-    return x + _lin(h, sd, pfx + ".mlp.fc2")
+    h = F.gelu(_lin_mm(_ln(x, sd, pfx + ".norm2"), sd, pfx + ".mlp.fc1"))
+    return x + _lin_mm(h, sd, pfx + ".mlp.fc2")
 
 
 def patch_merging(x, sd, pfx, res):
@@ -162,19 +226,19 @@ def patch_merging(x, sd, pfx, res):
     g = x.reshape(B, res // 2, 2, res // 2, 2, C)          # [B, Y, dy, X, dx, C]
     g = torch.cat([g[:, :, 0, :, 0], g[:, :, 1, :, 0], g[:, :, 0, :, 1], g[:, :, 1, :, 1]], dim=-1)
     g = g.reshape(B, L // 4, 4 * C)
-    return F.linear(_ln(g, sd, pfx + ".norm"), sd[pfx + ".reduction.weight"])
+    return _lin_mm(_ln(g, sd, pfx + ".norm"), sd, pfx + ".reduction")
 
 
 def patch_breakup(x, sd, pfx, res):
     """[B, res*res, 4C'] -> [B, 4*res*res, C']; swin_gnn.py:374-403 (scatter order :394-397)."""
     B, L, D = x.shape
     Co = D // 4
-    y = _ln(F.linear(x, sd[pfx + ".pre_linear.weight"]), sd, pfx + ".norm").reshape(B, res, res, 4, Co)
+    y = _ln(_lin_mm(x, sd, pfx + ".pre_linear"), sd, pfx + ".norm").reshape(B, res, res, 4, Co)
     out = torch.empty(B, res, 2, res, 2, Co, dtype=x.dtype)
     for k, (dy, dx) in enumerate(((0, 0), (1, 0), (0, 1), (1, 1))):
         out[:, :, dy, :, dx] = y[:, :, :, k]
     out = _ln(out.reshape(B, 4 * L, Co), sd, pfx + ".post_norm")
-    return F.linear(out, sd[pfx + ".post_linear.weight"])
+    return _lin_mm(out, sd, pfx + ".post_linear")
 
 
 def patch_embed(img, emb, sd, pfx, p):

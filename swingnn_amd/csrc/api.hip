@@ -107,7 +107,10 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
 // behind the attention core; otherwise the two halves run one after the other.  x_in == x_out is allowed.
 int mlp_impl(const swg_block* blk, int B, const float* x_in, float* x_out, void* ws, size_t ws_bytes, hipStream_t s);
 // Token counts from which the one-pass kernels (one workgroup per CU streaming a whole weight) beat the GEMM route.
+// Measured on the grid geometry (profiles/r03_batch_sweep*.jsonl): at 28 graphs (16128 tokens at C = 384) the one-pass
+// kernels win by 3.5 %, at 14 graphs (8064 tokens) the GEMM route wins by 6 %: the gate sits between, at 12288.
 // SWG_FUSED_MIN_TOKENS_PCT rescales all of them (tuning knob of scripts/, read once; 100 = the measured gates).
+constexpr size_t kFusedGate = 12288;
 static size_t fused_gate(size_t tokens) {
   static const long pct = [] {
     const char* e = getenv("SWG_FUSED_MIN_TOKENS_PCT");
@@ -119,21 +122,21 @@ static size_t fused_gate(size_t tokens) {
 bool fused_tail_ok(const swg_block* blk, int B) {
   const int C = blk->C, L = blk->res * blk->res;
   return blk->proj_mlp_img && blk->attn_img && mlp_stream_proj_supported(C) && L % 32 == 0 &&
-         (size_t)B * L >= fused_gate(16384) && wattn_ring_supported(C, blk->heads, blk->win, blk->res) &&
+         (size_t)B * L >= fused_gate(kFusedGate) && wattn_ring_supported(C, blk->heads, blk->win, blk->res) &&
          !wattn_ring_fuses_proj(C) && wattn_ring_wants_xn(C);
 }
 static bool mlp_stream_ok(const swg_block* blk, int B) {
   const int C = blk->C;
   const size_t T = (size_t)B * blk->res * blk->res;
-  return blk->mlp_img && !mlp_fused_supported(C) && mlp_stream_supported(C) && T >= fused_gate(C == 384 ? 16384 : 8192);
+  return blk->mlp_img && !mlp_fused_supported(C) && mlp_stream_supported(C) && T >= fused_gate(C == 384 ? kFusedGate : 8192);
 }
 static bool merge_fused_ok(const swg_merge* m, int B) {
   const size_t T4 = (size_t)B * (m->res / 2) * (m->res / 2);
-  return m->img && merge_fused_supported(m->C, m->res) && T4 >= fused_gate(16384);
+  return m->img && merge_fused_supported(m->C, m->res) && T4 >= fused_gate(kFusedGate);
 }
 static bool expand_fused_ok(const swg_breakup* u, int B) {
   const size_t T = (size_t)B * u->res * u->res;
-  return u->img_pre && u->img_post && expand_fused_supported(u->Cin) && T >= fused_gate(16384);
+  return u->img_pre && u->img_post && expand_fused_supported(u->Cin) && T >= fused_gate(kFusedGate);
 }
 int block_impl(const swg_block* blk, int B, const float* x_in, const float* cond, int cond_stride, float* x_out, void* ws,
                size_t ws_bytes, hipStream_t s) {

@@ -432,9 +432,14 @@ bool wattn_res_supported(int C, int heads, int win, int res) {
 }
 
 namespace {
+#ifndef RES_NW8
+#define RES_NW8 4   // waves per workgroup for 8x8 windows (A/B switch)
+#endif
 template <int WIN>
 int launch_res_t(const ResAttnArgs& a, int total, hipStream_t s) {
-  constexpr int C = 96, NW = 8, AHEAD = 3, NTM = (WIN * WIN + 15) / 16;
+  // 8x8 windows (64 tokens = 4 token tiles): with 8 waves per workgroup (two per SIMD, 256 registers each) the
+  // instance spills 256 B per lane; 4 waves (one per SIMD, the 512-register budget) hold everything in registers.
+  constexpr int C = 96, NW = (WIN == 8) ? RES_NW8 : 8, AHEAD = 3, NTM = (WIN * WIN + 15) / 16;
   const size_t lds = (size_t)a.heads * (4 * 2 * (C / 32)) * 1024 + AHEAD * 1024 + (size_t)(4 * C) * sizeof(float) +
                      (size_t)a.heads * NTM * NTM * 1024 +   // weights + read-ahead slack + biases + bias tiles
                      (size_t)(2 * C + NW * 2 * C) * sizeof(float);  // LayerNorm1 g / b + per-wave conditioning rows

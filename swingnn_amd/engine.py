@@ -598,8 +598,9 @@ _PROFILING = False           # set by prof.profiled()
 def launch_batch(B: int, N: int, cache=None) -> int:
     """Graphs per kernel launch of a pass over B graphs of N nodes (the part-batch when the pass is split).  With the
     NetCache given, a split that would push a stage below the token gate of a one-pass kernel (csrc/api.hip
-    fused_gate: e.g. grid B = 56 -> 2 x 28 graphs = 16128 tokens at C = 384, under the 16384 of the streamed MLP) is
-    refused: the part-batch must take the same kernels as the whole batch (swg_fused_op_count)."""
+    fused_gate: 12288 tokens; round 2 split grid B = 56 into 2 x 28 graphs = 16128 tokens at C = 384, under the
+    16384 of its gate, and the stage fell back to the GEMM route) is refused: the part-batch must take the same
+    kernels as the whole batch (swg_fused_op_count)."""
     parts = SPLIT_STREAMS
     if parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK:
         return B

@@ -53,9 +53,10 @@ def test_recorded_graph_survives_workspace_growth(golden_meta, monkeypatch):
         assert len(ent) == 4 and all(t.numel() >= E.get_cache(pre.model).ws_bytes(B1 // (2 if split else 1)) for t in ent[3])
 
 
-def test_split_never_drops_a_stage_below_a_fused_gate():
-    """grid N=384 dim-96: B = 112 runs as 2 x 56 graphs, but B = 56 must NOT run as 2 x 28 (16128 tokens at C = 384 is
-    under the 16384-token gate of the streamed MLP / projection tail: the stage would fall back to the GEMM route)."""
+def test_split_never_drops_a_stage_below_a_fused_gate(monkeypatch):
+    """grid N=384 dim-96: a pass is issued as two part-batches only when the part-batch takes the same one-pass kernels
+    as the whole batch (token gate 12288: 22 graphs at C = 384).  Round 2 split B = 56 into 2 x 28 graphs, under its
+    gate of 16384 tokens, and the C = 384 stage silently fell back to the GEMM route."""
     import swingnn_amd as S
     from swingnn_amd import engine as E
     net = S.SwinGNN(img_size=384, patch_size=4, in_chans=1, embed_dim=96, depths=[1, 1, 3, 1], num_heads=HEADS,
@@ -63,12 +64,15 @@ def test_split_never_drops_a_stage_below_a_fused_gate():
                     self_condition=True).to(DEV).eval()
     cache = E.get_cache(net)
     full = cache.fused_ops(112)
-    assert full > 0 and cache.fused_ops(56) == full and cache.fused_ops(28) < full
+    assert full > 0 and cache.fused_ops(56) == full and cache.fused_ops(28) == full and cache.fused_ops(20) < full
     assert E.launch_batch(112, 384, cache) == 56
-    assert E.launch_batch(56, 384, cache) == 56      # was 28 before round 3
-    assert E.launch_batch(58, 384, cache) == 29      # 29 x 576 = 16704 tokens: still above the gate
+    assert E.launch_batch(56, 384, cache) == 28      # 28 x 576 = 16128 tokens: above the gate, same kernels
     assert E.launch_batch(57, 384, cache) == 57      # odd batches never split
     assert E.launch_batch(8, 384, cache) == 8        # small work stays on one stream
+    monkeypatch.setattr(E, "SPLIT_MIN_WORK", 0)
+    assert E.launch_batch(40, 384, cache) == 40      # 2 x 20 graphs = 11520 tokens would drop under the gate: refused
+    assert E.launch_batch(44, 384, cache) == 22      # 22 x 576 = 12672: allowed
+    monkeypatch.undo()
     # the pass itself: bit-identical whichever way it is launched
     B = 56
     flags = (torch.arange(384)[None, :] < 361).float().expand(B, -1).contiguous().to(DEV)
