@@ -557,6 +557,21 @@ int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
 
 }  // namespace
 
+// The C = 192 instances live in a translation unit of their own (wattn_ring192.hip: this file compiled with
+// -DRING_TU_192 and -mllvm -amdgpu-mfma-vgpr-form=1).  With MFMA results in the architectural VGPRs the attention-core
+// instance fits 233 registers with no accumulation registers at all and loses 190 v_accvgpr moves per window
+// (361 -> 333 us per pass); the same flag costs the C = 384 instances 1 % (and k_mlp_stream<384,proj> spills under it),
+// and the flag is per translation unit.
+int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, hipStream_t s);
+
+#ifdef RING_TU_192
+int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, hipStream_t s) {
+  const RingAttnArgs& a = *static_cast<const RingAttnArgs*>(args);
+  if (win == 8)
+    return fuse_proj ? launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s) : launch_t<192, false, 4, 1, 5, true, 8>(a, nwg, s);
+  return fuse_proj ? launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s) : launch_t<192, false, 4, 1, 5, true, 6>(a, nwg, s);
+}
+#else
 bool wattn_ring_supported(int C, int heads, int win, int res) {
   return (C == 192 || C == 384) && heads * 32 == C && (win == 6 || win == 8) && res % win == 0;
 }
@@ -597,15 +612,14 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
                   row_bytes * T * C + gemm * C * C, s);
   int r;
   if (blk->win == 8) {
-    if (C == 192) r = wattn_ring_fuses_proj(C) ? launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s)
-                                               : launch_t<192, false, 4, 1, 5, true, 8>(a, nwg, s);
+    if (C == 192) r = launch_wattn_ring_c192(&a, nwg, 8, wattn_ring_fuses_proj(C), s);
     else r = launch_t<384, false, 5, 1, 5, true, 8>(a, nwg, s);
   } else {
-    if (C == 192) r = wattn_ring_fuses_proj(C) ? launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s)
-                                               : launch_t<192, false, 4, 1, 5, true, 6>(a, nwg, s);
+    if (C == 192) r = launch_wattn_ring_c192(&a, nwg, 6, wattn_ring_fuses_proj(C), s);
     else r = launch_t<384, false, 5, 1, 5, true, 6>(a, nwg, s);
   }
   if (r) return r;
   SWG_LAUNCH_CHECK();
   return 0;
 }
+#endif  // RING_TU_192

@@ -116,11 +116,12 @@ class GradSync:
         return extra
 
 
-def enable_gradient_sync(model, group=None, bucket_bytes: int = 64 << 20):
+def enable_gradient_sync(model, group=None, bucket_bytes: int = 64 << 20, min_world: int = 2):
     """Data-parallel training without the DDP wrapper: the HIP backward of `model` (a SwinGNN, or the `.model` of a
-    Precond) averages its gradients over `group` while it runs.  Pass ``None`` world (not initialised) to disable."""
+    Precond) averages its gradients over `group` while it runs.  Pass ``None`` world (not initialised) to disable.
+    `min_world=1` keeps the collectives on for a one-rank group (tests: the RCCL calls are issued and are identities)."""
     net = getattr(model, "model", model)
-    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) > 1:
+    if dist.is_available() and dist.is_initialized() and dist.get_world_size(group) >= min_world:
         net._swg_grad_sync = GradSync(group, bucket_bytes)
     else:
         net._swg_grad_sync = None
