@@ -145,6 +145,21 @@ __device__ __forceinline__ void lds_dma16(const void* gsrc_lane, unsigned lds_by
       : "v"(gsrc_lane), "s"(dst)
       : "memory");
 }
+// Same transfer with a WAVE-UNIFORM source base (SGPR pair) + a per-lane 32-bit byte offset (lane * 16 for a linear
+// 1-KiB piece): the address arithmetic of a piece stays on the scalar unit (the per-lane form costs a 64-bit VALU add,
+// a v_readfirstlane and often v_accvgpr reads of spilled constants per piece -- issue slots the MFMA groups need).
+__device__ __forceinline__ void lds_dma16_u(const void* gsrc_uniform, unsigned lane_byte_off, unsigned lds_byte_addr_uniform) {
+  unsigned keep;
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %3\n\t"
+      "s_nop 0\n\t"
+      "global_load_lds_dwordx4 %1, %2\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "v"(lane_byte_off), "s"(gsrc_uniform), "s"(lds_byte_addr_uniform)
+      : "memory");
+}
 __device__ __forceinline__ unsigned lds_addr(const void* p) {
   return (unsigned)(size_t)(const __attribute__((address_space(3))) void*)p;
 }

@@ -75,7 +75,16 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
   const int l15 = lane & 15, lg = lane >> 4;
   const int tok0 = blockIdx.x * 128 + wave * 32;
   const unsigned smem0 = lds_addr(smem);
+#ifdef SWG_STAMPS
+  const bool dbg = (blockIdx.x == 3 || blockIdx.x == gridDim.x / 2) && (wave == 0 || wave == 2);
+  const int dbgslot = (blockIdx.x == 3 ? 0 : 2) + (wave == 0 ? 0 : 1);
+#endif
+  STAMP(0);
 
+  // (A wave-uniform source base + scalar address math per piece -- common.h lds_dma16_u, wave index through
+  // v_readfirstlane -- removes 38 VALU instructions per chunk from this loop, yet the C = 384 PROJ instance ran 12 %
+  // SLOWER with the wave index made uniform, whichever DMA form followed (1410 -> 1584 us per pass; C = 192 +1 %): the
+  // register allocation of its prologue changes.  Measured round 3, not kept.)
   const char* img_lane = reinterpret_cast<const char*>(a.img) + lane * 16;
   // LDS-DMA piece i (of PIECES per wave) of image chunk `chunk` into the ring slot at byte offset buf_off
 #define STAGE_PIECE(chunk, buf_off, i)                                                        \
@@ -137,6 +146,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
         __builtin_amdgcn_sched_barrier(0);
       }
     }
+    STAMP(1);
     bf16x8 oa[2][KS];
 #pragma unroll
     for (int mt = 0; mt < 2; ++mt) {
@@ -169,6 +179,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
       bo = (bo == (NBUF - 1) * CHUNK_BYTES) ? 0u : bo + CHUNK_BYTES;
     }
   }
+  STAMP(2);
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
@@ -243,13 +254,21 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
     for (int s2 = 0; s2 < S2; ++s2) hb[mt][s2] = (u32x4){0u, 0u, 0u, 0u};
 
   if (!PROJ) __syncthreads();  // sb1 visible (the LDS-DMA above is inline asm: no vmcnt(0) is emitted for it here)
+  STAMP(3);
 #pragma nounroll
   for (int j = 0; j < NCH + 2; ++j) {
+#ifdef SWG_STAMPS
+    if (j < 50 && (j < 4 || j % 8 == 0)) STAMP(4 + j);
+#endif
     // chunk j has landed in every wave's view; NBUF-2 younger chunks may stay in flight
     // (the refill below runs in every iteration -- past the end it re-copies the last chunk into a dead slot --
     // so the count is the same every time)
+#ifndef MLP_DIAG_NODMA
     wait_vmcnt<(NBUF - 2) * PIECES>();
+#endif
+#ifndef MLP_DIAG_NOBARRIER
     __builtin_amdgcn_s_barrier();
+#endif
     asm volatile("" ::: "memory");  // no LDS read of this iteration may move above the barrier
     // every wave is now past its reads of the slot used one iteration ago: it is refilled piece by piece below
     const unsigned prev = (bo == 0) ? (NBUF - 1) * CHUNK_BYTES : bo - CHUNK_BYTES;
@@ -287,7 +306,9 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
       // -- fragment read AHEAD pairs ahead
       if (p + AHEAD < PAIRS) fr[(p + AHEAD) % (AHEAD + 1)] = *reinterpret_cast<const bf16x8*>(FRAG_PTR(p + AHEAD));
       // -- one LDS-DMA piece of chunk j+NBUF-1 every DMA_EVERY pairs
+#ifndef MLP_DIAG_NODMA    // diagnostic only: the chunk loop without refilling the ring
       if (p % DMA_EVERY == 1) STAGE_PIECE(next_chunk, prev, p / DMA_EVERY);
+#endif
       // -- GELU of chunk j-1 (gelu_f of common.h, spelled out): vector t = ht*2+mt (4 independent values) advances
       //    one LEVEL per slice, the vectors take turns, so dependent VALU ops are several pairs apart
 #pragma unroll
@@ -299,6 +320,11 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
         for (int r = 0; r < 4; ++r) {
           const int v = t * 4 + r;
           const float x = hcur[ht][mt][r];
+#ifdef MLP_DIAG_NOGELU   // diagnostic only (wrong results): the chunk loop without the GELU arithmetic
+          if (level == 9) gq[v] = x;
+          else if (level == 10 && (r & 1)) hbn[mt][ht >> 1][(ht & 1) * 2 + (r >> 1)] = pack_bf16x2(gq[v - 1], gq[v]);
+          continue;
+#endif
           if (level == 0) gs[v] = x * x;
           else if (level == 1) gq[v] = fmaf(-3.228973355362541e-06f, gs[v], 8.823775715427473e-05f);
           else if (level == 2) gq[v] = fmaf(gq[v], gs[v], 0.00036027710302732885f);
@@ -326,6 +352,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
     bo = (bo == (NBUF - 1) * CHUNK_BYTES) ? 0u : bo + CHUNK_BYTES;
   }
 #undef STAGE_PIECE
+  STAMP(60);
   wait_vmcnt<0>();  // the trailing refills must have landed before the workgroup's LDS is released
 
   // ---- epilogue: the accumulators hold x + b2 + fc2(...): a lane stores 32 contiguous bytes per k-step ----
@@ -337,6 +364,7 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
     for (int nt = 0; nt < NT; ++nt)
       *reinterpret_cast<f32x4*>(a.out + (size_t)tok * C + 32 * (nt >> 1) + 8 * lg + 4 * (nt & 1)) = acc[nt][mt];
   }
+  STAMP(61);
 }
 
 template <int C, int HC, int NBUF, int LB, bool PROJ>
