@@ -148,6 +148,22 @@ int32_t swg_fused_op_count(const swg_net* net, int32_t B);
 int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float* x, const float* node_flags,
                         const float* labels, int32_t labels_uniform, const float* self_cond, float* out,
                         float* sym_err, void* ws, size_t ws_bytes, void* stream);
+/* swg_precond_forward with the conditioning rows handed in.  cond_rows: device [Bc, cond_total] fp32 (Bc = 1 when
+ * labels_uniform, else B), row b = the stacked (scale | shift) vectors of every block for label b, as swg_cond_table
+ * (or swg_noise_embed) produces them; NULL = compute them here (then identical to swg_precond_forward).  In sampling
+ * sigma is one value per Heun step for the whole batch (runner/mcmc_sampler/edm.py:180) and the 511 model calls of a
+ * sample use only num_steps distinct values, so the sampler builds the table once per sample() and every pass skips
+ * the noise-embedding chain (PositionalEmbedding + map_layer0/1, model/swin_gnn/swin_gnn.py:757-760, and the stacked
+ * affine layers :238-239 / :574-575): four small dependent launches at the head of each pass.  Same arithmetic, same
+ * bits.  `labels` is still read (preconditioning coefficients). */
+int swg_precond_forward_cond(const swg_net* net, int32_t B, int32_t mode, const float* x, const float* node_flags,
+                             const float* labels, int32_t labels_uniform, const float* cond_rows,
+                             const float* self_cond, float* out, float* sym_err, void* ws, size_t ws_bytes, void* stream);
+/* Conditioning rows for n labels at once: cond_rows[i] = affine_all(silu(map1(silu(map0(PosEmb(c_noise_i)))))) with
+ * c_noise = ln(sigma)/4 (mode 1, runner/objectives/edm.py:126) or the label itself (mode 0).  ws: scratch of at least
+ * 4 * n * (5 + C0 + 2 * SWG_NOISE_EMB) bytes + 1 KiB. */
+int swg_cond_table(const swg_net* net, int32_t n, int32_t mode, const float* labels, float* cond_rows, void* ws,
+                   size_t ws_bytes, void* stream);
 
 /* ---- op-level entry points (each replaces one reference module's forward) ------------ */
 /* a8: PositionalEmbedding + map_layer0/1 (:507-513, :757-760) and every affine layer:

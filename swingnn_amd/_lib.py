@@ -106,6 +106,8 @@ SYMBOLS = {
     "swg_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),
     "swg_fused_op_count": (_i32, [C.POINTER(SwgNet), _i32]),
     "swg_precond_forward": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_precond_forward_cond": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
+    "swg_cond_table": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _sz, _fp]),
     "swg_noise_embed": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _sz, _fp]),
     "swg_patch_embed_fwd": (C.c_int, [C.POINTER(SwgNet), _i32, _fp, _fp, _fp, _i32, _fp, _i32, _fp, _fp]),
     "swg_wattn_fwd": (C.c_int, [C.POINTER(SwgBlock), _i32, _fp, _fp, _i32, _fp, _fp, _sz, _fp]),

@@ -518,9 +518,9 @@ int swg_readout_sym_precond_fwd(const swg_net* net, int32_t B, const float* tok,
   return readout_impl(net, B, tok, x, node_flags, coef, out, sym_err, ws, ws_bytes, (hipStream_t)stream);
 }
 
-int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float* x, const float* node_flags,
-                        const float* labels, int32_t labels_uniform, const float* self_cond, float* out,
-                        float* sym_err, void* ws, size_t ws_bytes, void* stream) {
+int swg_precond_forward_cond(const swg_net* net, int32_t B, int32_t mode, const float* x, const float* node_flags,
+                             const float* labels, int32_t labels_uniform, const float* cond_rows,
+                             const float* self_cond, float* out, float* sym_err, void* ws, size_t ws_bytes, void* stream) {
   hipStream_t s = (hipStream_t)stream;
   if (!net || !x || !node_flags || !labels || !out) return SWG_E_NULL;
   if (B <= 0 || (mode != 0 && mode != 1)) return SWG_E_SHAPE;
@@ -528,11 +528,36 @@ int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float
   int r = carve_trunk(net, B, labels_uniform, ws, ws_bytes, 0, &tb);
   if (r) return r;
   if ((r = launch_edm_coef(labels, B, labels_uniform, mode, tb.coef, tb.cnoise, s))) return r;
-  if ((r = embed_impl(net, tb.Bc, tb.cnoise, tb.cond, tb.sw, tb.sb, s))) return r;
+  if (cond_rows) {
+    tb.cond = const_cast<float*>(cond_rows);  // read-only from here on
+  } else if ((r = embed_impl(net, tb.Bc, tb.cnoise, tb.cond, tb.sw, tb.sb, s))) {
+    return r;
+  }
   if ((r = launch_patch_embed(net, B, x, self_cond, tb.coef + 2, 4, tb.cond, tb.cstride, tb.A, s))) return r;
   const float* cur = nullptr;
   if ((r = run_trunk(net, B, tb, &cur, s))) return r;
   return readout_impl(net, B, cur, x, node_flags, tb.coef, out, sym_err, tb.sw, tb.sb, s);
+}
+
+int swg_precond_forward(const swg_net* net, int32_t B, int32_t mode, const float* x, const float* node_flags,
+                        const float* labels, int32_t labels_uniform, const float* self_cond, float* out,
+                        float* sym_err, void* ws, size_t ws_bytes, void* stream) {
+  return swg_precond_forward_cond(net, B, mode, x, node_flags, labels, labels_uniform, nullptr, self_cond, out, sym_err,
+                                  ws, ws_bytes, stream);
+}
+
+int swg_cond_table(const swg_net* net, int32_t n, int32_t mode, const float* labels, float* cond_rows, void* ws,
+                   size_t ws_bytes, void* stream) {
+  hipStream_t s = (hipStream_t)stream;
+  if (!net || !labels || !cond_rows) return SWG_E_NULL;
+  if (n <= 0 || (mode != 0 && mode != 1)) return SWG_E_SHAPE;
+  Carver cv(ws, ws_bytes);
+  float* coef = cv.take<float>((size_t)n * 4);
+  float* cnoise = cv.take<float>((size_t)n);
+  if (!cv.ok) return SWG_E_WORKSPACE;
+  int r;
+  if ((r = launch_edm_coef(labels, n, 0, mode, coef, cnoise, s))) return r;
+  return embed_impl(net, n, cnoise, cond_rows, cv.p, cv.left, s);
 }
 
 size_t swg_nodeadj_workspace_bytes(const swg_net* net, const swg_nodeadj* na, int32_t B) {

@@ -87,9 +87,14 @@ __global__ __launch_bounds__(256, LB) void k_mlp_stream(MlpArgs a) {
   // register allocation of its prologue changes.  Measured round 3, not kept.)
   const char* img_lane = reinterpret_cast<const char*>(a.img) + lane * 16;
   // LDS-DMA piece i (of PIECES per wave) of image chunk `chunk` into the ring slot at byte offset buf_off
+  // C = 192: the LDS destination of a piece is computed on the scalar unit (one v_readfirstlane per kernel instead of
+  // a v_add + v_readfirstlane per piece: 710 -> 694 us per pass).  The C = 384 PROJ instance runs 10 % SLOWER with
+  // exactly this change (1434 -> 1584 us, reproducibly, also with a wave-uniform source base): left as it was.
+  constexpr bool DST_SCALAR = (C == 192);
+  const unsigned dst_wave = DST_SCALAR ? __builtin_amdgcn_readfirstlane(smem0 + wave * 1024) : 0u;
 #define STAGE_PIECE(chunk, buf_off, i)                                                        \
   lds_dma16(img_lane + (size_t)(chunk) * CHUNK_BYTES + ((i) * 4 + wave) * 1024,               \
-            smem0 + (buf_off) + ((i) * 4 + wave) * 1024)
+            DST_SCALAR ? dst_wave + (buf_off) + (i) * 4096 : smem0 + (buf_off) + ((i) * 4 + wave) * 1024)
   // the token rows are requested BEFORE the ring is primed: loads return in order, so rows issued behind two chunks
   // of LDS-DMA would wait for them (C = 384: 192 registers of raw rows do not fit beside the LayerNorm temporaries)
   constexpr bool ROWS_FIRST = C <= 192 && !PROJ;

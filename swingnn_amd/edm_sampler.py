@@ -93,6 +93,12 @@ class EDMSampler(GeneralSampler):
         # (tests/test_gpu_parity.py::test_graph_replayed_sampler_is_bit_identical).
         self.use_graphs = False
         self._graph_bufs = {}
+        # Opt-in (not a reference option): compute the conditioning rows (noise embedding + every block's scale / shift)
+        # of the num_steps sigma_hat values once per sample() instead of at the head of each of the ~766 network passes
+        # (the reference re-evaluates map_layer0/1 and the affine layers per model call, swin_gnn.py:757-760).  Same
+        # arithmetic, bit-identical samples (tests/test_gpu_parity.py::test_precomputed_conditioning_is_bit_identical).
+        # Off by default, like reuse_passes, so that the default run launches everything the reference evaluates.
+        self.precompute_conditioning = False
 
     # overridable so that parity tests can inject pre-drawn noise
     def _randn_like(self, x):
@@ -164,6 +170,14 @@ class EDMSampler(GeneralSampler):
         was_graphs = getattr(inner, "use_graphs", False)
         if graphs:
             inner.use_graphs = True
+        # sigma_hat is one value per step for the whole batch (edm.py:180): the conditioning rows of all num_steps
+        # values are computed once here, and the 511 model calls skip their noise-embedding launches (same arithmetic,
+        # same bits; engine.register_cond_rows).  Graph-replayed passes read sigma from one fixed slot and keep the
+        # in-pass embedding.
+        cond_token = cond_cache = None
+        if self.precompute_conditioning and masked_model and gt is None and not graphs:
+            cond_cache = E.get_cache(inner.model)
+            cond_token = E.register_cond_rows(cond_cache, 1, sig_all)
         try:
             for i, (t_hat, coef, h, t_prime) in enumerate(consts):
                 x_cur = x_next
@@ -210,6 +224,8 @@ class EDMSampler(GeneralSampler):
         finally:
             if graphs:
                 inner.use_graphs = was_graphs
+            if cond_token is not None:
+                E.release_cond_rows(cond_cache, cond_token)
         adjs = x_next.cpu()  # syncs the stream
         assert float(sym_acc.item()) < 1e-2, "sampler state lost symmetry"
         if masked_model:

@@ -505,12 +505,14 @@ class NetCache:
         self.layers = layers
         self._ws_bytes = {}
         self._fused_ops = {}
+        self.cond_rows = {}    # (mode, address of a batch-uniform label) -> precomputed conditioning row (register_cond_rows)
         self.table = RefreshTable(keep.registry, dev)
 
     def refresh(self, model):
         """Rewrite every derived operand in place from the current parameters (after an optimizer step): one
         swg_refresh_derived launch for the bf16 operands, a few torch copies for the small fp32 ones.  Pointers and
         descriptors stay valid."""
+        self.cond_rows.clear()   # conditioning rows were computed from the old affine / map_layer weights
         self.table.run()
         with torch.no_grad():
             torch.cat([m.weight for m in self._aff_mods], dim=0, out=self._aw)
@@ -619,9 +621,41 @@ def _side_streams(idx: int, n: int):
 
 def _launch_pass(cache, B, mode, x, flags, labels, labels_uniform, sc, out, sym_err):
     ws = workspace(x.device, cache.ws_bytes(B))
-    L.check(L.lib.swg_precond_forward(C.byref(cache.net), B, mode, x.data_ptr(), flags.data_ptr(), labels.data_ptr(),
-                                      int(labels_uniform), _ptr(sc), out.data_ptr(), _ptr(sym_err), ws.data_ptr(),
-                                      ws.numel(), stream_ptr()), "swg_precond_forward")
+    cond = cache.cond_rows.get((mode, labels.data_ptr())) if (labels_uniform and cache.cond_rows) else None
+    L.check(L.lib.swg_precond_forward_cond(C.byref(cache.net), B, mode, x.data_ptr(), flags.data_ptr(),
+                                           labels.data_ptr(), int(labels_uniform), _ptr(cond), _ptr(sc), out.data_ptr(),
+                                           _ptr(sym_err), ws.data_ptr(), ws.numel(), stream_ptr()),
+            "swg_precond_forward_cond")
+
+
+def conditioning_table(cache, mode: int, labels: torch.Tensor) -> torch.Tensor:
+    """[n, cond_total] conditioning rows of the n labels (swg_cond_table): what every pass with one batch-uniform
+    label would compute at its head.  register_cond_rows() makes the passes use them."""
+    labels = _as_f32(labels).reshape(-1)
+    n = labels.numel()
+    rows = torch.empty((n, cache.net.cond_total), dtype=torch.float32, device=labels.device)
+    ws = torch.empty(4 * n * (5 + cache.net.C0 + 2 * 512) + 4096, dtype=torch.uint8, device=labels.device)
+    L.check(L.lib.swg_cond_table(C.byref(cache.net), n, mode, labels.data_ptr(), rows.data_ptr(), ws.data_ptr(),
+                                 ws.numel(), stream_ptr()), "swg_cond_table")
+    return rows
+
+
+def register_cond_rows(cache, mode: int, labels: torch.Tensor):
+    """Precompute the conditioning rows of the batch-uniform labels a sampler is about to use (one per Heun step) and
+    key them by the ADDRESS of each label: a pass whose (uniform) label tensor starts at labels[i] then skips its
+    noise-embedding launches.  Returns a token for release_cond_rows().  The rows are tied to the current parameter
+    values: NetCache.refresh() drops them."""
+    labels = _as_f32(labels).reshape(-1)
+    rows = conditioning_table(cache, mode, labels)
+    keys = [(mode, labels.data_ptr() + 4 * i) for i in range(labels.numel())]
+    for i, k in enumerate(keys):
+        cache.cond_rows[k] = rows[i]
+    return (labels, rows, keys)       # keeps the label vector (its addresses) and the table alive
+
+
+def release_cond_rows(cache, token):
+    for k in token[2]:
+        cache.cond_rows.pop(k, None)
 
 
 def network_pass(cache: NetCache, mode: int, x, node_flags, labels, labels_uniform: bool, self_cond, out=None,

@@ -401,6 +401,48 @@ def test_pass_reuse_is_bit_identical(S, golden_meta):
         print(f"{net_name}: {counts[0]} passes by default, {counts[1]} with reuse ({steps} Heun steps)")
 
 
+def test_precomputed_conditioning_is_bit_identical(S, golden_meta, monkeypatch):
+    """EDMSampler.precompute_conditioning (opt-in): the conditioning rows of all sigma_hat values come from ONE
+    swg_cond_table call per sample() and every pass runs through swg_precond_forward_cond without its noise-embedding
+    launches.  Same seeds -> bit-identical samples, for one-stream and part-batch passes; and the table itself equals
+    the rows the per-pass path computes."""
+    from swingnn_amd import engine as E
+    for net_name, steps, B, split in (("ego60", 12, 3, False), ("grid192", 3, 2, True)):
+        nc = NET_CASES[net_name]
+        cfg = nc["cfg"]
+        monkeypatch.setattr(E, "SPLIT_MIN_WORK", 0 if split else 1 << 60)
+        pre = build_precond(S, net_name, golden_meta, "init", seed=7)
+        flags = filler.node_flags("flags", B, cfg["img_size"], nc["n_lo"], nc["n_hi"], 7).to(DEV)
+        outs = []
+        for pc in (False, True):
+            smp = S.EDMSampler(num_steps=steps, clip_samples=False, clip_samples_min=-1.0, clip_samples_max=1.0,
+                               clip_samples_scope="x_0", self_condition=cfg["self_condition"], dev=DEV)
+            smp.precompute_conditioning = pc
+            torch.manual_seed(11)
+            torch.cuda.manual_seed(11)
+            np.random.seed(11)
+            outs.append(smp.sample(pre, flags))
+        assert torch.equal(outs[0], outs[1]), f"{net_name}: max diff {float((outs[0] - outs[1]).abs().max())}"
+        cache = E.get_cache(pre.model)
+        assert not cache.cond_rows                       # released at the end of sample()
+        # a registered row is what the pass would compute: D with and without it, per-sample labels as a third view
+        x = filler.sym_adj("x", B, cfg["img_size"], flags.cpu(), 5, 2.0).to(DEV)
+        sig = torch.tensor([0.3, 1.7, 40.0], device=DEV)
+        monkeypatch.setattr(np.random, "rand", lambda: 0.75)
+        plain = [pre(x, flags, sig[i:i + 1].expand(B)).clone() for i in range(3)]
+        tok = E.register_cond_rows(cache, 1, sig)
+        try:
+            assert len(cache.cond_rows) == 3
+            n0 = E.PASS_COUNT
+            cached = [pre(x, flags, sig[i:i + 1].expand(B)).clone() for i in range(3)]
+            assert E.PASS_COUNT - n0 == 3
+        finally:
+            E.release_cond_rows(cache, tok)
+        for a, b in zip(plain, cached):
+            assert torch.equal(a, b)
+        monkeypatch.undo()
+
+
 def test_graph_replayed_sampler_is_bit_identical(S, golden_meta, monkeypatch):
     """EDMSampler.use_graphs (opt-in): every network pass is one HIP-graph launch recorded on first use.  Same seeds ->
     the samples must be bit-identical to the eager run, for the unsplit pass, for the pass recorded with its two
