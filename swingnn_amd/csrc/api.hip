@@ -123,7 +123,7 @@ bool fused_tail_ok(const swg_block* blk, int B) {
   const int C = blk->C, L = blk->res * blk->res;
   return blk->proj_mlp_img && blk->attn_img && mlp_stream_proj_supported(C) && L % 32 == 0 &&
          (size_t)B * L >= fused_gate(kFusedGate) && wattn_ring_supported(C, blk->heads, blk->win, blk->res) &&
-         !wattn_ring_fuses_proj(C) && wattn_ring_wants_xn(C);
+         !wattn_ring_fuses_proj(C);
 }
 static bool mlp_stream_ok(const swg_block* blk, int B) {
   const int C = blk->C;
@@ -149,7 +149,8 @@ int block_impl(const swg_block* blk, int B, const float* x_in, const float* cond
     bf16* xn = cv.take<bf16>((size_t)T * Cp);
     bf16* o = cv.take<bf16>((size_t)T * Cp);
     if (!cv.ok) return SWG_E_WORKSPACE;
-    if ((r = launch_cond_ln(x_in, T, C, L, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, nullptr, xn, Cp, s)))
+    if (!wattn_ring_wants_xn(C)) xn = nullptr;  // conditioning + LayerNorm1 run in the attention kernel's prologue
+    else if ((r = launch_cond_ln(x_in, T, C, L, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, nullptr, xn, Cp, s)))
       return r;
     if ((r = launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, nullptr, o, Cp, s))) return r;
     return launch_mlp_stream_proj(C, T, L, x_in, o, Cp, cond, cond_stride, blk->cond_off, blk->proj.b, x_out,

@@ -567,6 +567,8 @@ int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, h
 #ifdef RING_TU_192
 int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, hipStream_t s) {
   const RingAttnArgs& a = *static_cast<const RingAttnArgs*>(args);
+  if (!a.xn && !fuse_proj)   // conditioning + LayerNorm1 inside the kernel (no k_row<cond_ln> pass in front)
+    return win == 8 ? launch_t<192, false, 4, 1, 5, false, 8>(a, nwg, s) : launch_t<192, false, 4, 1, 5, false, 6>(a, nwg, s);
   if (win == 8)
     return fuse_proj ? launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s) : launch_t<192, false, 4, 1, 5, true, 8>(a, nwg, s);
   return fuse_proj ? launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s) : launch_t<192, false, 4, 1, 5, true, 6>(a, nwg, s);
@@ -588,7 +590,15 @@ bool wattn_ring_fuses_proj(int C) {
   return C == 192 && fuse192;
 }
 
-bool wattn_ring_wants_xn(int C) { return true; }  // in-kernel LN (PRE_LN = false) measured slower at C = 192
+// C = 384 (and the fused-projection form at C = 192) take the rows conditioned + normalised by k_row<cond_ln>.  The
+// attention-core instance at C = 192 has the registers to do it in its prologue (SWG_RING192_INKERNEL_LN, A/B knob).
+bool wattn_ring_wants_xn(int C) {
+  static const bool inkernel192 = [] {
+    const char* e = getenv("SWG_RING192_INKERNEL_LN");
+    return e && e[0] == '1';
+  }();
+  return !(C == 192 && inkernel192 && !wattn_ring_fuses_proj(C));
+}
 
 // FUSE_PROJ geometries write x_out (`out`); C = 384 writes o (bf16 [T, ldo]) for the projection GEMM.  C >= 192 take
 // the rows already conditioned + normalised (xn, bf16 [T, ldxn], from k_row<cond_ln>): in-kernel LayerNorm of a
