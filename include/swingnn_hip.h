@@ -63,6 +63,11 @@ typedef struct swg_block {
    * immediately followed by the mlp_stream image (swingnn_amd/engine.py proj_mlp_image).  NULL -> projection GEMM +
    * MLP kernel. */
   const void* proj_mlp_img;
+  /* optional derived cache for k_wattn_ring at 6x6 windows: the relative-position bias (:121-124) of every head in
+   * ACCUMULATOR layout, [heads][3 key tiles][3 query tiles][64 lanes] x 4 fp32, scaled by log2(e), -3e38 on padded
+   * keys (swg_rpb_tiles).  The kernel loads a head's nine tiles straight into the accumulators of S^T = K Q^T one head
+   * ahead.  NULL -> the bias is read from an LDS table per score. */
+  const float* rpb_tiles;
 } swg_block;
 
 /* PatchMerging (:298-335) at input resolution res x res, input width C */
@@ -136,6 +141,10 @@ size_t swg_workspace_bytes(const swg_net* net, int32_t B);
  * runner/sampler/sampler_utils.py:254-258) compares the count of the part-batch with the count of the whole batch and
  * does not split when the part-batch would fall below a gate.  <0: SWG_E_*. */
 int32_t swg_fused_op_count(const swg_net* net, int32_t B);
+
+/* Relative-position bias of one block as accumulator-layout tiles (see swg_block.rpb_tiles): rpb [(2win-1)^2, heads]
+ * -> tiles [heads][NTM][NTM][64][4] fp32 with NTM = ceil(win*win / 16).  Derived cache, rebuilt when rpb changes. */
+int swg_rpb_tiles(const float* rpb, int32_t heads, int32_t win, float* tiles, void* stream);
 
 /* ---- whole network pass -------------------------------------------------------------- *
  * mode 1: Precond.forward core, model/precond/precond.py:47-51 (edm branch of

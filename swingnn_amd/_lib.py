@@ -29,7 +29,7 @@ class SwgBlock(C.Structure):
                 ("heads", C.c_int32), ("cond_off", C.c_int32),
                 ("ln1", SwgLn), ("ln2", SwgLn),
                 ("qkv", SwgLin), ("proj", SwgLin), ("fc1", SwgLin), ("fc2", SwgLin),
-                ("rpb", _fp), ("mlp_img", _fp), ("attn_img", _fp), ("proj_mlp_img", _fp)]
+                ("rpb", _fp), ("mlp_img", _fp), ("attn_img", _fp), ("proj_mlp_img", _fp), ("rpb_tiles", _fp)]
 
 
 class SwgMerge(C.Structure):
@@ -105,6 +105,7 @@ SYMBOLS = {
     "swg_version": (C.c_int, []),
     "swg_workspace_bytes": (_sz, [C.POINTER(SwgNet), _i32]),
     "swg_fused_op_count": (_i32, [C.POINTER(SwgNet), _i32]),
+    "swg_rpb_tiles": (C.c_int, [_fp, _i32, _i32, _fp, _fp]),
     "swg_precond_forward": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _i32, _fp, _fp, _fp, _fp, _sz, _fp]),
     "swg_precond_forward_cond": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _i32, _fp, _fp, _fp, _fp, _fp, _sz, _fp]),
     "swg_cond_table": (C.c_int, [C.POINTER(SwgNet), _i32, _i32, _fp, _fp, _fp, _sz, _fp]),

@@ -41,6 +41,7 @@ struct RingAttnArgs {
   const float* proj_b;  // [C]
   const float* rpb;     // [(2w-1)^2, heads]
   int B, res, shift, heads;
+  const float* rpb_tiles;  // BT: bias in accumulator layout, [heads][NTM][NTM][64][4] (swg_rpb_tiles)
 };
 
 template <int N>
@@ -50,7 +51,7 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 __host__ __device__ constexpr int ring_unit(int frags_head) { return frags_head % 24 == 0 ? 24 : frags_head; }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false>
 __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   // window geometry: NTOK tokens in NTM 16-token MFMA tiles, KSP 32-deep k-steps over the keys; the last tile holds
   // REM valid tokens (WIN = 6: 36 tokens = 3 tiles, REM 4; WIN = 8: 64 tokens = 4 full tiles)
@@ -76,7 +77,14 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   // 6x6 windows: the 36 bias values of a lane (3 x 3 tile pairs x 4 accumulator rows) are read straight into the
   // accumulators of S^T = K Q^T through 36 head-invariant LDS offsets kept in registers; entry NB of a head's table is
   // the key padding (-3e38).  8x8 windows (64 offsets) keep the index arithmetic: C = 192 is at the register limit.
-  constexpr bool BIAS_REGS = (WIN == 6);
+  // BT (6x6 windows with swg_block.rpb_tiles): the nine bias tiles of a head are loaded from global memory straight
+  // into the S accumulators' registers at the top of the head (inline asm, counted vmcnt: the loads are older than
+  // every LDS-DMA piece of the head's slabs, so they have landed when that many operations are outstanding) -- no LDS
+  // reads for the bias at all.  The 36 ds_read_b32 per head with their 2-way bank conflicts were 10 % of the C = 384
+  // kernel (ablation: 712 -> 643 us per pass without them).
+  constexpr bool BIAS_REGS = (WIN == 6) && !BT;
+  constexpr int NBT = BT ? NTM * NTM : 0;                       // bias loads per head
+  constexpr int NAFTER = (3 * SLAB - 2) / DMA_EVERY + 1;        // LDS-DMA pieces issued between them and S
   constexpr int NBP = NB + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_qkvb = reinterpret_cast<float*>(smem + RING_BYTES);  // [3C], q part pre-scaled
@@ -276,7 +284,9 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 #define GROUP(G, BODY)                                                                                              \
   {                                                                                                                 \
     if ((G) % UNIT == 0) {                                                                                          \
-      wait_vmcnt<(NBUF - 3) * PIECES>();                                                                            \
+      /* the first boundary after the head's bias loads: they are younger than the unit the wait is about */       \
+      if ((G) == UNIT) wait_vmcnt<(NBUF - 3) * PIECES + NBT>();                                                     \
+      else wait_vmcnt<(NBUF - 3) * PIECES>();                                                                       \
       __builtin_amdgcn_s_barrier();                                                                                 \
       asm volatile("" ::: "memory");                                                                                \
     }                                                                                                               \
@@ -313,6 +323,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
     if (h < 3) STAMP(3 + 8 * h);
     // ---- V [tokens x 32] = A Wv^T (tokens on rows: directly the A operand of O^T = V^T P^T) ----
     bf16x8 qf[NTM], kf[NTM], vf[2][KSP];
+    f32x4 bz[BT ? NTM * NTM : 1];
     {
       f32x4 va[NTM][2];
 #pragma unroll
@@ -323,6 +334,13 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       for (int p = 0; p < SLAB; ++p) {
         GROUP(p, _Pragma("unroll") for (int mt = 0; mt < NTM; ++mt) va[mt][p & 1] =
                      __builtin_amdgcn_mfma_f32_16x16x32_bf16(xa[mt][p >> 1], w, va[mt][p & 1], 0, 0, 0));
+        if (BT && p == 0) {   // after the unit-boundary wait of group 0, before the first DMA piece of the head
+          const float* bt = a.rpb_tiles + ((size_t)h * (NTM * NTM * 64) + lane) * 4;
+#pragma unroll
+          for (int t = 0; t < NBT; ++t)
+            asm volatile("global_load_dwordx4 %0, %1, off" : "=v"(bz[BT ? t : 0]) : "v"(bt + t * 256) : "memory");
+          __builtin_amdgcn_sched_barrier(0);
+        }
       }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
@@ -393,15 +411,33 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       // ---- S^T = K Q^T (log2 domain), softmax over keys (rows) per query (lane) ----
     float p[NTM][NTM][4];
     const char* rp = reinterpret_cast<const char*>(s_rpb + h * NBP);
-    if (BIAS_REGS) {
+    if (BT) {
+      static_assert(!BT || NTM == 3, "nine tiles");
+      // the loads are older than the NAFTER pieces issued since: done once at most that many operations are pending
+      asm volatile("s_waitcnt vmcnt(%9)"
+                   : "+v"(bz[0]), "+v"(bz[BT ? 1 : 0]), "+v"(bz[BT ? 2 : 0]), "+v"(bz[BT ? 3 : 0]), "+v"(bz[BT ? 4 : 0]),
+                     "+v"(bz[BT ? 5 : 0]), "+v"(bz[BT ? 6 : 0]), "+v"(bz[BT ? 7 : 0]), "+v"(bz[BT ? 8 : 0])
+                   : "n"(NAFTER));
+#pragma unroll
+      for (int kt = 0; kt < NTM; ++kt)
+#pragma unroll
+        for (int qt = 0; qt < NTM; ++qt) {
+          f32x4 z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], bz[BT ? kt * NTM + qt : 0], 0, 0, 0);
+          p[kt][qt][0] = z[0]; p[kt][qt][1] = z[1]; p[kt][qt][2] = z[2]; p[kt][qt][3] = z[3];
+        }
+    } else if (BIAS_REGS) {
 #pragma unroll
       for (int kt = 0; kt < NTM; ++kt)
 #pragma unroll
         for (int qt = 0; qt < NTM; ++qt) {
           f32x4 z;
+#ifdef RING_DIAG_NOBIAS   // diagnostic only (wrong results)
+          z = (f32x4){0.f, 0.f, 0.f, 0.f};
+#else
 #pragma unroll
           for (int r = 0; r < 4; ++r)
             z[r] = *reinterpret_cast<const float*>(rp + boff[BIAS_REGS ? kt : 0][BIAS_REGS ? qt : 0][r]);
+#endif
           z = __builtin_amdgcn_mfma_f32_16x16x32_bf16(kf[kt], qf[qt], z, 0, 0, 0);
           p[kt][qt][0] = z[0]; p[kt][qt][1] = z[1]; p[kt][qt][2] = z[2]; p[kt][qt][3] = z[3];
         }
@@ -436,6 +472,10 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
     }
     if (h < 3) STAMP(7 + 8 * h);
     float inv_sum[NTM];
+#ifdef RING_DIAG_NOSOFTMAX   // diagnostic only (wrong results): no max / exp / sum
+#pragma unroll
+    for (int qt = 0; qt < NTM; ++qt) inv_sum[qt] = 1.0f;
+#else
 #pragma unroll
     for (int qt = 0; qt < NTM; ++qt) {
       float mx = -3.0e38f;
@@ -456,6 +496,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       sum = rows_sum(sum);
       inv_sum[qt] = fast_rcp(sum);
     }
+#endif
 
     if (h < 3) STAMP(8 + 8 * h);
     // ---- O^T = V^T P^T ; channel slot h*32 + 8*lg + e of a row holds head dim pi(lg, e) ----
@@ -545,13 +586,13 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   }
 }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false>
 int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
   constexpr int UNIT = ring_unit((FUSE_PROJ ? 4 : 3) * 2 * (C / 32));
   const size_t lds = (size_t)NBUF * UNIT * 1024 + (size_t)(4 * C + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
-  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>, (int)((int)lds))) return e;
-  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN>), dim3(nwg), dim3(256), lds, s, a);
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT>, (int)((int)lds))) return e;
+  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT>), dim3(nwg), dim3(256), lds, s, a);
   return 0;
 }
 
@@ -571,6 +612,7 @@ int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, h
     return win == 8 ? launch_t<192, false, 4, 1, 5, false, 8>(a, nwg, s) : launch_t<192, false, 4, 1, 5, false, 6>(a, nwg, s);
   if (win == 8)
     return fuse_proj ? launch_t<192, true, 4, 1, 5, true, 8>(a, nwg, s) : launch_t<192, false, 4, 1, 5, true, 8>(a, nwg, s);
+  if (a.rpb_tiles && !fuse_proj) return launch_t<192, false, 4, 1, 5, true, 6, true>(a, nwg, s);
   return fuse_proj ? launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s) : launch_t<192, false, 4, 1, 5, true, 6>(a, nwg, s);
 }
 #else
@@ -611,7 +653,8 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   if (wattn_ring_wants_xn(C) && (!xn || ldxn % 8)) return SWG_E_NULL;
   const int nW = (blk->res / blk->win) * (blk->res / blk->win);
   RingAttnArgs a = {x, xn, ldxn, out, o, ldo, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b,
-                    (const bf16*)blk->attn_img, blk->qkv.b, blk->proj.b, blk->rpb, B, blk->res, blk->shift, blk->heads};
+                    (const bf16*)blk->attn_img, blk->qkv.b, blk->proj.b, blk->rpb, B, blk->res, blk->shift, blk->heads,
+                    blk->win == 6 ? blk->rpb_tiles : nullptr};
   const int nwg = cdiv(B * nW, 4);
   const double T = (double)B * blk->res * blk->res;
   const double gemm = wattn_ring_fuses_proj(C) ? 8.0 : 6.0;
@@ -626,9 +669,42 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
     else r = launch_t<384, false, 5, 1, 5, true, 8>(a, nwg, s);
   } else {
     if (C == 192) r = launch_wattn_ring_c192(&a, nwg, 6, wattn_ring_fuses_proj(C), s);
-    else r = launch_t<384, false, 5, 1, 5, true, 6>(a, nwg, s);
+    else r = a.rpb_tiles ? launch_t<384, false, 5, 1, 5, true, 6, true>(a, nwg, s)
+                         : launch_t<384, false, 5, 1, 5, true, 6>(a, nwg, s);
   }
   if (r) return r;
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
+
+// ---- swg_rpb_tiles: relative-position bias as accumulator-layout tiles (derived cache of swg_block.rpb_tiles) ----
+namespace {
+__global__ void k_rpb_tiles(const float* __restrict__ rpb, int heads, int win, int ntm, float* __restrict__ tiles) {
+  const int ntok = win * win, w2 = 2 * win - 1;
+  const int total = heads * ntm * ntm * 64;
+  for (int e = blockIdx.x * blockDim.x + threadIdx.x; e < total; e += gridDim.x * blockDim.x) {
+    const int ln = e & 63, t = e >> 6;
+    const int qt = t % ntm, kt = (t / ntm) % ntm, hh = t / (ntm * ntm);
+    const int i = min(qt * 16 + (ln & 15), ntok - 1);
+    const int iy = i / win, ix = i - iy * win;
+    float v[4];
+    for (int r = 0; r < 4; ++r) {
+      const int j = kt * 16 + 4 * (ln >> 4) + r;
+      const int jy = j / win, jx = j - jy * win;
+      v[r] = j < ntok ? rpb[((iy - jy + win - 1) * w2 + (ix - jx + win - 1)) * heads + hh] * 1.44269504088896340736f
+                      : -3.0e38f;
+    }
+    *reinterpret_cast<float4*>(tiles + (size_t)e * 4) = make_float4(v[0], v[1], v[2], v[3]);
+  }
+}
+}  // namespace
+
+extern "C" int swg_rpb_tiles(const float* rpb, int32_t heads, int32_t win, float* tiles, void* stream) {
+  if (!rpb || !tiles) return SWG_E_NULL;
+  if (heads <= 0 || win <= 0 || win > 8) return SWG_E_SHAPE;
+  const int ntm = (win * win + 15) / 16;
+  hipLaunchKernelGGL(k_rpb_tiles, dim3(cdiv(heads * ntm * ntm * 64, 256)), dim3(256), 0, (hipStream_t)stream, rpb, heads,
+                     win, ntm, tiles);
   SWG_LAUNCH_CHECK();
   return 0;
 }

@@ -72,6 +72,7 @@ class Keep:
 
     def __init__(self, registry=None):
         self.items = []
+        self.rpb_tiles = []   # (rpb fp32 view, heads, window, tiles) of blocks with swg_block.rpb_tiles
         # when not None: every derived bf16 operand is recorded as (mode, sources, dst[, idx]) so that it can be
         # rewritten in place after an optimizer step (RefreshTable / swg_refresh_derived)
         self.registry = registry
@@ -344,11 +345,29 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
         pimg, img = _ptr(whole), _ptr(vb)
     elif USE_FUSED_MLP and blk.dim in STREAM_MLP_HC:
         img = _ptr(keep.image(mlp_stream_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight), STREAM_MLP_HC[blk.dim]))
+    rpb = keep(_f32(blk.attn.relative_position_bias_table))
+    tiles = None
+    if aimg is not None and blk.dim in (192, 384) and blk.window_size == 6 and USE_RPB_TILES and rpb.is_cuda:
+        # bias of every head in accumulator layout (swg_rpb_tiles): k_wattn_ring loads it straight into the S registers
+        ntm = (blk.window_size ** 2 + 15) // 16
+        tiles = keep(torch.empty(blk.num_heads * ntm * ntm * 64 * 4, dtype=torch.float32, device=rpb.device))
+        keep.rpb_tiles.append((rpb, blk.num_heads, blk.window_size, tiles))
+        L.check(L.lib.swg_rpb_tiles(rpb.data_ptr(), blk.num_heads, blk.window_size, tiles.data_ptr(), stream_ptr()),
+                "swg_rpb_tiles")
     return L.SwgBlock(blk.dim, blk.input_resolution[0], blk.window_size, blk.shift_size, blk.num_heads, cond_off,
                       keep.ln(blk.norm1), keep.ln(blk.norm2),
                       keep.lin(blk.attn.qkv.weight, blk.attn.qkv.bias), keep.lin(blk.attn.proj.weight, blk.attn.proj.bias),
                       keep.lin(blk.mlp.fc1.weight, blk.mlp.fc1.bias), keep.lin(blk.mlp.fc2.weight, blk.mlp.fc2.bias),
-                      keep.f32(blk.attn.relative_position_bias_table), img, aimg, pimg)
+                      _ptr(rpb), img, aimg, pimg, _ptr(tiles))
+
+
+USE_RPB_TILES = os.environ.get("SWG_RPB_TILES", "1") == "1"   # A/B knob
+
+
+def build_rpb_tiles(keep):
+    """(Re)build the bias tiles of every block that has them from the current relative_position_bias_table."""
+    for rpb, heads, win, tiles in keep.rpb_tiles:
+        L.check(L.lib.swg_rpb_tiles(rpb.data_ptr(), heads, win, tiles.data_ptr(), stream_ptr()), "swg_rpb_tiles")
 
 
 MERGE_FUSED_NC = {96: 32, 192: 16}   # output features per 24-KiB weight chunk of csrc/merge_fused.hip, per input width
@@ -514,6 +533,7 @@ class NetCache:
         descriptors stay valid."""
         self.cond_rows.clear()   # conditioning rows were computed from the old affine / map_layer weights
         self.table.run()
+        build_rpb_tiles(self.keep)
         with torch.no_grad():
             torch.cat([m.weight for m in self._aff_mods], dim=0, out=self._aw)
             torch.cat([m.bias for m in self._aff_mods], dim=0, out=self._ab)
