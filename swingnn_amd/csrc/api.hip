@@ -121,7 +121,7 @@ static size_t fused_gate(size_t tokens) {
 }
 bool fused_tail_ok(const swg_block* blk, int B) {
   const int C = blk->C, L = blk->res * blk->res;
-  return blk->proj_mlp_img && blk->attn_img && mlp_stream_proj_supported(C) && L % 32 == 0 &&
+  return blk->proj_mlp_img && blk->attn_img && mlp_stream_proj_supported(C) &&
          (size_t)B * L >= fused_gate(kFusedGate) && wattn_ring_supported(C, blk->heads, blk->win, blk->res) &&
          !wattn_ring_fuses_proj(C);
 }

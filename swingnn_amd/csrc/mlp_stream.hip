@@ -406,7 +406,7 @@ int launch_mlp_stream_proj(int C, int T, int L, const float* x_in, const bf16* o
                            const float* b2, const float* g, const float* b, hipStream_t s) {
   if (!mlp_stream_proj_supported(C)) return SWG_E_UNSUPPORTED;
   if (T <= 0) return 0;
-  if (L <= 0 || L % 32 || T % L || ldo < C || ldo % 8) return SWG_E_SHAPE;  // a wave's 32 tokens lie in one graph
+  if (L <= 0 || T % L || ldo < C || ldo % 8) return SWG_E_SHAPE;  // the conditioning row is looked up per token
   if (!x_in || !o || !cond || !proj_b || !out || !img) return SWG_E_NULL;
   MlpArgs a = {x_in, out, img, b1, b2, g, b, T, o, ldo, proj_b, cond, cond_stride, cond_off, L};
   SwgProfScope ps(C == 384 ? KID_MLP_PROJ_384 : KID_MLP_PROJ_192, 18.0 * T * (double)C * C,

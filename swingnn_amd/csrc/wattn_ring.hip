@@ -51,12 +51,16 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 __host__ __device__ constexpr int ring_unit(int frags_head) { return frags_head % 24 == 0 ? 24 : frags_head; }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false, int PACK = 1>
 __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   // window geometry: NTOK tokens in NTM 16-token MFMA tiles, KSP 32-deep k-steps over the keys; the last tile holds
-  // REM valid tokens (WIN = 6: 36 tokens = 3 tiles, REM 4; WIN = 8: 64 tokens = 4 full tiles)
-  constexpr int NTOK = WIN * WIN, NTM = (NTOK + 15) / 16, KSP = (NTM + 1) / 2, REM = NTOK - (NTM - 1) * 16;
+  // REM valid tokens (WIN = 6: 36 tokens = 3 tiles, REM 4; WIN = 8: 64 tokens = 4 full tiles; WIN = 4: one tile).
+  // PACK > 1 (WIN = 2): PACK consecutive windows share the wave's one tile (token slot i = window i / NTOKW, token
+  // i % NTOKW); the scores between different windows of the tile are excluded like padding keys.
+  constexpr int NTOKW = WIN * WIN, NTOK = NTOKW * PACK;
+  constexpr int NTM = (NTOK + 15) / 16, KSP = (NTM + 1) / 2, REM = NTOK - (NTM - 1) * 16;
   static_assert(REM % 4 == 0, "key padding is per lane group");
+  static_assert(PACK == 1 || (NTM == 1 && !BT && PRE_LN && !FUSE_PROJ), "packed windows: one tile, attention core only");
   constexpr int KS = C / 32;
   constexpr int NT = C / 16;
   constexpr int SLAB = 2 * KS;                       // fragments per slab (== NT)
@@ -95,14 +99,15 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   const int l15 = lane & 15, lg = lane >> 4;
   const int nwx = a.res / WIN, nW = nwx * nwx;
   const int total = a.B * nW;
-  int wi_g = blockIdx.x * 4 + wave;
-  const bool live = wi_g < total;
-  wi_g = min(wi_g, total - 1);
+  const int wi_0 = (blockIdx.x * 4 + wave) * PACK;   // the wave's first window
+  const bool live = wi_0 < total;
+  const int wi_g = min(wi_0, total - 1);
   const int b = wi_g / nW, wi = wi_g - b * nW;
   const int wy = wi / nwx, wx = wi - wy * nwx;
   const int Ltok = a.res * a.res;
   // region ids differ inside a window only in the last window row / column of a shifted block
-  const bool need_mask = __builtin_amdgcn_readfirstlane((int)(a.shift > 0 && (wy == nwx - 1 || wx == nwx - 1))) != 0;
+  const bool need_mask = __builtin_amdgcn_readfirstlane(
+      (int)(a.shift > 0 && (PACK > 1 || wy == nwx - 1 || wx == nwx - 1))) != 0;
   const int nunits = UH * a.heads;
 #ifdef SWG_STAMPS
   const bool dbg = (blockIdx.x == 8 || blockIdx.x == gridDim.x / 2) && (wave == 0 || wave == 2);
@@ -123,7 +128,18 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   // ---- per-lane token bookkeeping; the softmax tables are built after the LayerNorm block so that they are not
   // live across its register peak ----
   int tokq[NTM];
+  const int b_w = b, wy_w = wy, wx_w = wx;
   auto coords = [&](int i, int& rel_y, int& rel_x, int& rid, int& tok) {
+    int b = b_w, wy = wy_w, wx = wx_w;            // the token's window: the wave's, or window i / NTOKW of its pack
+    if (PACK > 1) {
+      const int sub = i / NTOKW;
+      i -= sub * NTOKW;
+      const int wg = min(wi_0 + sub, total - 1);
+      b = wg / nW;
+      const int w = wg - b * nW;
+      wy = w / nwx;
+      wx = w - wy * nwx;
+    }
     const int iy = i / WIN, ix = i - iy * WIN;
     const int ys = wy * WIN + iy, xs = wx * WIN + ix;
     int y = ys + a.shift, x = xs + a.shift;  // shifted[y] = x[(y+s) mod H]  (roll by -s, :248)
@@ -458,6 +474,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
           for (int r = 0; r < 4; ++r) {
             float sv = p[kt][qt][r] + *reinterpret_cast<const float*>(rp + (qrel[qt] - krel[kt][r]));
             if (kt == NTM - 1) sv += kpad;
+            if (PACK > 1 && (4 * lg + r) / NTOKW != l15 / NTOKW) sv = -3.0e38f;   // another window of the pack
             p[kt][qt][r] = sv;
           }
     }
@@ -526,7 +543,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       f[4] = (bf16)(o1[0] * is); f[5] = (bf16)(o1[1] * is); f[6] = (bf16)(o1[2] * is); f[7] = (bf16)(o1[3] * is);
       of[qt] = f;
       if (!FUSE_PROJ) {
-        if (live && qt * 16 + l15 < NTOK)
+        if (live && qt * 16 + l15 < NTOK && (PACK == 1 || wi_0 + l15 / NTOKW < total))
           *reinterpret_cast<bf16x8*>(a.o + (size_t)tokq[qt] * a.ldo + h * 32 + 8 * lg) = f;
       }
     }
@@ -586,13 +603,13 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   }
 }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false, int PACK = 1>
 int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
   constexpr int UNIT = ring_unit((FUSE_PROJ ? 4 : 3) * 2 * (C / 32));
   const size_t lds = (size_t)NBUF * UNIT * 1024 + (size_t)(4 * C + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
-  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT>, (int)((int)lds))) return e;
-  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT>), dim3(nwg), dim3(256), lds, s, a);
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK>, (int)((int)lds))) return e;
+  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK>), dim3(nwg), dim3(256), lds, s, a);
   return 0;
 }
 
@@ -608,6 +625,9 @@ int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, h
 #ifdef RING_TU_192
 int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, hipStream_t s) {
   const RingAttnArgs& a = *static_cast<const RingAttnArgs*>(args);
+  // small windows (attention core on pre-normalised rows only): 4x4 = one MFMA tile per wave, 2x2 = four windows per tile
+  if (win == 4) return launch_t<192, false, 4, 1, 5, true, 4>(a, nwg, s);
+  if (win == 2) return launch_t<192, false, 4, 1, 5, true, 2, false, 4>(a, nwg, s);
   if (!a.xn && !fuse_proj)   // conditioning + LayerNorm1 inside the kernel (no k_row<cond_ln> pass in front)
     return win == 8 ? launch_t<192, false, 4, 1, 5, false, 8>(a, nwg, s) : launch_t<192, false, 4, 1, 5, false, 6>(a, nwg, s);
   if (win == 8)
@@ -616,8 +636,12 @@ int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, h
   return fuse_proj ? launch_t<192, true, 4, 1, 5, true, 6>(a, nwg, s) : launch_t<192, false, 4, 1, 5, true, 6>(a, nwg, s);
 }
 #else
+// 6x6 / 8x8 windows: every form.  4x4 (one MFMA tile per wave) and 2x2 windows (four windows per tile): the attention
+// core on pre-normalised rows only.
 bool wattn_ring_supported(int C, int heads, int win, int res) {
-  return (C == 192 || C == 384) && heads * 32 == C && (win == 6 || win == 8) && res % win == 0;
+  if (!((C == 192 || C == 384) && heads * 32 == C && res % win == 0)) return false;
+  if (win == 6 || win == 8) return true;
+  return (win == 4 || win == 2) && !wattn_ring_fuses_proj(C) && wattn_ring_wants_xn(C);
 }
 // C = 384: the projection accumulators do not fit beside the LN1 fragments.  C = 192: they fit, but the kernel runs
 // faster as the attention core alone (36 instead of 48 fragments per head, no 144 accumulator registers, no shortcut
@@ -655,7 +679,7 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   RingAttnArgs a = {x, xn, ldxn, out, o, ldo, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b,
                     (const bf16*)blk->attn_img, blk->qkv.b, blk->proj.b, blk->rpb, B, blk->res, blk->shift, blk->heads,
                     blk->win == 6 ? blk->rpb_tiles : nullptr};
-  const int nwg = cdiv(B * nW, 4);
+  const int nwg = cdiv(B * nW, blk->win == 2 ? 16 : 4);
   const double T = (double)B * blk->res * blk->res;
   const double gemm = wattn_ring_fuses_proj(C) ? 8.0 : 6.0;
   // algorithmic bytes per token and channel: fused projection: x in (4, shortcut) + out (4) [+ 2 for the pre-normalised
@@ -664,7 +688,11 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   SwgProfScope ps(C == 384 ? KID_WATTN_RING_384 : KID_WATTN_RING, gemm * T * C * C + 4.0 * T * (blk->win * blk->win) * C,
                   row_bytes * T * C + gemm * C * C, s);
   int r;
-  if (blk->win == 8) {
+  if (blk->win == 4 || blk->win == 2) {
+    if (C == 192) r = launch_wattn_ring_c192(&a, nwg, blk->win, false, s);
+    else r = blk->win == 4 ? launch_t<384, false, 5, 1, 5, true, 4>(a, nwg, s)
+                           : launch_t<384, false, 5, 1, 5, true, 2, false, 4>(a, nwg, s);
+  } else if (blk->win == 8) {
     if (C == 192) r = launch_wattn_ring_c192(&a, nwg, 8, wattn_ring_fuses_proj(C), s);
     else r = launch_t<384, false, 5, 1, 5, true, 8>(a, nwg, s);
   } else {

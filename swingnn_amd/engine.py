@@ -276,6 +276,7 @@ RING192_FUSE_PROJ = os.environ.get("SWG_RING192_FUSE_PROJ", "0") == "1"
 # channel counts with the fused attention-tail + MLP kernel (csrc/mlp_stream.hip, PROJ form)
 PROJ_MLP_DIMS = (384,) if RING192_FUSE_PROJ else (384, 192)
 USE_FUSED_ATTN = True
+RING_SMALL_WINDOWS = os.environ.get("SWG_RING_SMALL_WINDOWS", "1") == "1"   # A/B knob: 4x4 / 2x2 windows at C = 192 / 384
 
 
 def _rho(Cdim: int, device) -> torch.Tensor:
@@ -326,8 +327,9 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
     img = None
     aimg = None
     # fused attention geometries (csrc/wattn_res.hip: C = 96, windows 4 / 6 / 8; csrc/wattn_ring.hip: C = 192 / 384,
-    # windows 6 / 8); the weight image does not depend on the window size
-    wins = (4, 6, 8) if blk.dim == 96 else (6, 8)
+    # windows 6 / 8 and, as the attention core alone, 4 / 2); the weight image does not depend on the window size
+    wins = (4, 6, 8) if blk.dim == 96 else ((2, 4, 6, 8) if RING_SMALL_WINDOWS and not RING_ATTN_FUSED_PROJ.get(blk.dim)
+                                            else (6, 8))
     if (USE_FUSED_ATTN and blk.dim in RING_ATTN_FUSED_PROJ and blk.window_size in wins
             and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % blk.window_size == 0):
         aimg = _ptr(keep.image(wattn_ring_image, (blk.attn.qkv.weight, blk.attn.proj.weight), blk.num_heads,

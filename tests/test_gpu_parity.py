@@ -126,6 +126,60 @@ def test_swin_block_vs_oracle(S, name):
     rel_close(got, want.cpu(), max_rel=2e-2, mean_rel=2e-3)
 
 
+# 4x4 and 2x2 windows at C = 192 / 384 (community-small / QM9 / ZINC deep stages): k_wattn_ring's small-window instances
+# (one 16-token MFMA tile per wave; 2x2: four windows packed into the tile, cross-window scores excluded), shifted and
+# ragged window counts, below the one-pass gate (attention core + projection GEMM) and above it (core + k_mlp_stream PROJ)
+SMALL_WINDOW_CASES = {
+    "r8_w4_s2_c192": dict(C=192, res=8, heads=6, window=4, shift=2, B=3, seed=81, tail=False),
+    "r4_w4_s0_c384": dict(C=384, res=4, heads=12, window=4, shift=0, B=5, seed=82, tail=False),
+    "r4_w2_s1_c384": dict(C=384, res=4, heads=12, window=2, shift=1, B=3, seed=83, tail=False),
+    "r2_w24_c384": dict(C=384, res=2, heads=12, window=24, shift=0, B=7, seed=84, tail=False),     # clamp -> w=2, 7 windows
+    "r8_w2_s1_c192": dict(C=192, res=8, heads=6, window=2, shift=1, B=1, seed=85, tail=False),
+    "r8_w4_s2_c192_tail": dict(C=192, res=8, heads=6, window=4, shift=2, B=200, seed=86, tail=True),
+    "r4_w4_s0_c384_tail": dict(C=384, res=4, heads=12, window=4, shift=0, B=800, seed=87, tail=True),
+    "r4_w2_s1_c384_tail": dict(C=384, res=4, heads=12, window=2, shift=1, B=801, seed=88, tail=True),
+}
+
+
+@pytest.mark.parametrize("name", list(SMALL_WINDOW_CASES))
+def test_small_window_blocks(S, name):
+    from swingnn_amd import prof
+    c = SMALL_WINDOW_CASES[name]
+    w, s = O.eff_window(c["res"], c["window"], c["shift"])
+    full = H.block_state(c["C"], c["heads"], w, c["seed"])
+    blk = load(S.SwinTransformerBlock(c["C"], 512, (c["res"],) * 2, c["heads"], c["window"], c["shift"]),
+               strip(full, "blk."))
+    x = filler.uniform("x", (c["B"], c["res"] ** 2, c["C"]), c["seed"])
+    emb = filler.uniform("emb", (c["B"], 512), c["seed"])
+    with prof.profiled():
+        out = blk(x.to(DEV), emb.to(DEV))
+        torch.cuda.synchronize()
+        ran = set(prof.read())
+    assert f"k_wattn_ring<{c['C']}>" in ran and "k_wattn_core" not in ran, ran
+    assert (f"k_mlp_stream<{c['C']},proj>" in ran) == c["tail"], ran
+    ref = O.swin_block(x, emb, full, "blk", c["res"], c["heads"], c["window"], c["shift"])
+    rel_close(out, ref)
+    with O.bf16_operands():
+        ref16 = O.swin_block(x, emb, full, "blk", c["res"], c["heads"], c["window"], c["shift"])
+    rel_close(out, ref16, **BLOCK_BF16_BARS)
+    # the unfused route (qkv GEMM -> k_wattn_core -> projection GEMM) on the same block: same answer to bf16 rounding
+    from swingnn_amd import engine as E
+    saved = E.USE_FUSED_ATTN
+    E.USE_FUSED_ATTN = False
+    try:
+        blk2 = load(S.SwinTransformerBlock(c["C"], 512, (c["res"],) * 2, c["heads"], c["window"], c["shift"]),
+                    strip(full, "blk."))
+        with prof.profiled():
+            out2 = blk2(x.to(DEV), emb.to(DEV))
+            torch.cuda.synchronize()
+            assert "k_wattn_core" in set(prof.read())
+    finally:
+        E.USE_FUSED_ATTN = saved
+    with O.bf16_operands(q="raw"):   # that route rounds the unscaled query rows the qkv GEMM wrote
+        ref16r = O.swin_block(x, emb, full, "blk", c["res"], c["heads"], c["window"], c["shift"])
+    rel_close(out2, ref16r, **BLOCK_BF16_BARS)
+
+
 def test_block_attention_half_only(S):
     """swg_wattn_fwd alone (no MLP) against the oracle's attention half, shifted 6x6 windows."""
     import ctypes as C
