@@ -42,7 +42,7 @@ class bf16_operands:
     """Context manager: round matrix-product operands to bfloat16 like the HIP kernels do.  `q`: where the query is
     rounded -- "log2" (fused window kernels: q * hd^-1/2 * log2 e), "raw" (GEMM route: the unscaled qkv row) or
     "auto" (per block, by the geometry rule of csrc/api.hip: fused for head_dim 32, C in {96, 192, 384}, windows
-    4 / 6 / 8 at C = 96 and 2 / 4 / 6 / 8 above).  At
+    4 / 6 / 8 at C = 96 and 2 / 4 / 6 / 8 above; head_dim 20 at C = 60 / 120 / 240 with windows 2 / 4 / 8).  At
     unit-gain weights the softmax is sharp enough that this choice alone moves a block's output by 3e-3 of its scale."""
 
     def __init__(self, q="auto"):
@@ -172,7 +172,8 @@ def window_attention(xw, sd, pfx, heads, w, mask):
     qkv = _lin_mm(xw, sd, pfx + ".qkv").reshape(B_, n, 3, heads, hd).permute(2, 0, 3, 1, 4)
     q_mode = _BF16_Q
     if q_mode == "auto":   # which route the library takes for this geometry (csrc/api.hip wattn_impl)
-        fused = hd == 32 and C in (96, 192, 384) and w in ((4, 6, 8) if C == 96 else (2, 4, 6, 8))
+        fused = (hd == 32 and C in (96, 192, 384) and w in ((4, 6, 8) if C == 96 else (2, 4, 6, 8))
+                 or hd == 20 and C in (60, 120, 240) and w in (2, 4, 8))
         q_mode = "log2" if fused else "raw"
     if _BF16 and q_mode == "log2":
         # the fused window kernels keep the scores in the log2 domain: q is rounded as q * hd^-1/2 * log2(e)

@@ -75,15 +75,18 @@ int wattn_impl(const swg_block* blk, int B, const float* x_in, const float* cond
     if (wattn_ring_fuses_proj(C))
       return launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, x_out, nullptr, 0, s);
     // two kernels: attention core -> o (bf16, head-dim slots in accumulator order), then the projection GEMM on the
-    // slot-permuted Wproj (stored behind the fragment stream) with the shortcut recomputed in its epilogue
-    bf16* o = cv.take<bf16>((size_t)T * Cp);
+    // slot-permuted Wproj (stored behind the fragment stream) with the shortcut recomputed in its epilogue.
+    // head_dim 20: o has a 32-slot group per head (CO = heads * 32 columns, slots 20..31 zero) and Wproj matching
+    // zero columns, behind a stream of 3 * CO rows of Cp (= C rounded up to 32) channels.
+    const int CO = blk->heads * 32;
+    bf16* o = cv.take<bf16>((size_t)T * CO);
     if (!cv.ok) return SWG_E_WORKSPACE;
-    if ((r = launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, nullptr, o, Cp, s))) return r;
-    const bf16* wp = (const bf16*)blk->attn_img + (size_t)3 * C * C;
+    if ((r = launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, nullptr, o, CO, s))) return r;
+    const bf16* wp = (const bf16*)blk->attn_img + (size_t)3 * CO * Cp;
     GemmEpi e2 = {};
     e2.bias = blk->proj.b; e2.residual = x_in; e2.ldr = C; e2.out_f32 = x_out; e2.ldo = C;
     e2.cond = cond; e2.cond_stride = cond_stride; e2.cond_off = blk->cond_off; e2.cond_L = L;
-    return launch_gemm(o, Cp, wp, T, C, Cp, e2, s);
+    return launch_gemm(o, CO, wp, T, C, CO, e2, s);
   }
   Carver cv(ws, ws_bytes);
   float* x1 = cv.take<float>((size_t)T * C);

@@ -39,6 +39,7 @@ enum SwgKernelId {
   KID_MERGE_FUSED,
   KID_EXPAND_FUSED,
   KID_MLP_PROJ_192,
+  KID_WATTN_RING_HD20,
   KID_COUNT
 };
 

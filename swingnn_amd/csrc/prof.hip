@@ -31,7 +31,7 @@ const char* kNames[KID_COUNT] = {"k_gemm_nt<32>",    "k_wattn_core",  "k_row<con
                                  "bwd_rows",       "k_wattn_bwd",   "k_adam_ema",
                                  "k_nodeadj",      "k_gemm_nt<64>", "k_gemm_nt_big",  "k_gemm_tn",
                                  "k_mlp_stream<384>", "k_wattn_ring<384>", "k_mlp_stream<384,proj>", "k_merge_linear", "k_expand_fused",
-                                 "k_mlp_stream<192,proj>"};
+                                 "k_mlp_stream<192,proj>", "k_wattn_ring<hd20>"};
 
 void drain() {  // caller holds the lock; synchronises the recorded events
   for (size_t i = 0; i < P.used; ++i) {

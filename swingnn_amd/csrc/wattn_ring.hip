@@ -51,8 +51,13 @@ __device__ __forceinline__ void wait_vmcnt() {
 
 __host__ __device__ constexpr int ring_unit(int frags_head) { return frags_head % 24 == 0 ? 24 : frags_head; }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false, int PACK = 1>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false, int PACK = 1, int HD = 32>
 __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
+  // HD < 32 (head_dim 20: the dim-60 networks): C is the channel count rounded up to the 32-deep k-step (the rows of
+  // k_row<cond_ln> are zero-padded to it), every head occupies a 32-slot group whose slots HD..31 are zero in the
+  // weight image (engine.py wattn_ring_image), and o has heads x 32 columns for a projection GEMM over the padded slots.
+  static_assert(HD == 32 || (PRE_LN && !FUSE_PROJ && !BT), "padded heads: attention core on pre-normalised rows only");
+  const int CO = HD == 32 ? C : a.heads * 32;        // q / k / v slot groups
   // window geometry: NTOK tokens in NTM 16-token MFMA tiles, KSP 32-deep k-steps over the keys; the last tile holds
   // REM valid tokens (WIN = 6: 36 tokens = 3 tiles, REM 4; WIN = 8: 64 tokens = 4 full tiles; WIN = 4: one tile).
   // PACK > 1 (WIN = 2): PACK consecutive windows share the wave's one tile (token slot i = window i / NTOKW, token
@@ -92,8 +97,8 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   constexpr int NBP = NB + 1;
   extern __shared__ __attribute__((aligned(16))) char smem[];
   float* s_qkvb = reinterpret_cast<float*>(smem + RING_BYTES);  // [3C], q part pre-scaled
-  float* s_pb = s_qkvb + 3 * C;                                 // [C]
-  float* s_rpb = s_pb + C;                                      // [heads][NB] * log2(e)
+  float* s_pb = s_qkvb + 3 * CO;                                // [C]
+  float* s_rpb = s_pb + CO;                                     // [heads][NB] * log2(e)
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int l15 = lane & 15, lg = lane >> 4;
@@ -123,7 +128,9 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
             smem0 + (slot_off) + ((i) * 4 + wave) * 1024)
 
   constexpr float LOG2E = 1.44269504088896340736f;
-  constexpr float QSCALE = 0.17677669529663687f * LOG2E;  // 32^-0.5 * log2(e): scores live in the log2 domain
+  // head_dim^-0.5 * log2(e): scores live in the log2 domain
+  constexpr float QSCALE = (HD == 32 ? 0.17677669529663687f : HD == 20 ? 0.22360679774997896f : 0.f) * LOG2E;
+  static_assert(HD == 32 || HD == 20, "head dims with a tabulated scale");
 
   // ---- per-lane token bookkeeping; the softmax tables are built after the LayerNorm block so that they are not
   // live across its register peak ----
@@ -186,7 +193,14 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       for (int ks = 0; ks < KS; ++ks) xa[mt][ks] = *reinterpret_cast<const bf16x8*>(row + 32 * ks);
     }
   }
-  for (int i = tid; i < 3 * C; i += 256) s_qkvb[i] = a.qkv_b[i] * (i < C ? QSCALE : 1.0f);
+  if (HD == 32) {
+    for (int i = tid; i < 3 * C; i += 256) s_qkvb[i] = a.qkv_b[i] * (i < C ? QSCALE : 1.0f);
+  } else {   // slot part * CO + h * 32 + d  <-  qkv bias part * (heads * HD) + h * HD + d, zero for the padded slots
+    for (int i = tid; i < 3 * CO; i += 256) {
+      const int part = i / CO, r = i - part * CO, hh = r >> 5, d = r & 31;
+      s_qkvb[i] = d < HD ? a.qkv_b[(part * a.heads + hh) * HD + d] * (part == 0 ? QSCALE : 1.0f) : 0.f;
+    }
+  }
   if (FUSE_PROJ)
     for (int i = tid; i < C; i += 256) s_pb[i] = a.proj_b[i];
   for (int i = tid; i < NBP * a.heads; i += 256) {
@@ -360,7 +374,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
       }
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
-        const float bv = s_qkvb[2 * C + h * 32 + dt * 16 + l15];
+        const float bv = s_qkvb[2 * CO + h * 32 + dt * 16 + l15];
 #pragma unroll
         for (int ks = 0; ks < KSP; ++ks) {
           bf16x8 f;
@@ -410,8 +424,8 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
         GROUP(2 * SLAB + p, _Pragma("unroll") for (int mt = 0; mt < NTM; ++mt) ka[p & 1][mt] =
                                 __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, xa[mt][p >> 1], ka[p & 1][mt], 0, 0, 0));
       }
-      const float4 bk0 = *reinterpret_cast<const float4*>(s_qkvb + C + h * 32 + 4 * lg);
-      const float4 bk1 = *reinterpret_cast<const float4*>(s_qkvb + C + h * 32 + 16 + 4 * lg);
+      const float4 bk0 = *reinterpret_cast<const float4*>(s_qkvb + CO + h * 32 + 4 * lg);
+      const float4 bk1 = *reinterpret_cast<const float4*>(s_qkvb + CO + h * 32 + 16 + 4 * lg);
 #pragma unroll
       for (int mt = 0; mt < NTM; ++mt) {
         bf16x8 g;
@@ -603,13 +617,14 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   }
 }
 
-template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false, int PACK = 1>
+template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false, int PACK = 1, int HD = 32>
 int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
   constexpr int UNIT = ring_unit((FUSE_PROJ ? 4 : 3) * 2 * (C / 32));
-  const size_t lds = (size_t)NBUF * UNIT * 1024 + (size_t)(4 * C + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
+  const int CO = HD == 32 ? C : a.heads * 32;
+  const size_t lds = (size_t)NBUF * UNIT * 1024 + (size_t)(4 * CO + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
-  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK>, (int)((int)lds))) return e;
-  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK>), dim3(nwg), dim3(256), lds, s, a);
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK, HD>, (int)((int)lds))) return e;
+  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK, HD>), dim3(nwg), dim3(256), lds, s, a);
   return 0;
 }
 
@@ -621,8 +636,27 @@ int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
 // (361 -> 333 us per pass); the same flag costs the C = 384 instances 1 % (and k_mlp_stream<384,proj> spills under it),
 // and the flag is per translation unit.
 int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, hipStream_t s);
+// head_dim 20 (C = 60 / 120 / 240, rows padded to CK = 64 / 128 / 256): wattn_ring_hd20.hip (-DRING_TU_HD20)
+int launch_wattn_ring_hd20(const void* args, int nwg, int CK, int win, hipStream_t s);
 
-#ifdef RING_TU_192
+#if defined(RING_TU_HD20)
+namespace {
+template <int CK>
+int launch_hd20(const RingAttnArgs& a, int nwg, int win, hipStream_t s) {
+  if (win == 8) return launch_t<CK, false, 4, 1, 5, true, 8, false, 1, 20>(a, nwg, s);
+  if (win == 4) return launch_t<CK, false, 4, 1, 5, true, 4, false, 1, 20>(a, nwg, s);
+  if (win == 2) return launch_t<CK, false, 4, 1, 5, true, 2, false, 4, 20>(a, nwg, s);
+  return SWG_E_UNSUPPORTED;
+}
+}  // namespace
+int launch_wattn_ring_hd20(const void* args, int nwg, int CK, int win, hipStream_t s) {
+  const RingAttnArgs& a = *static_cast<const RingAttnArgs*>(args);
+  if (CK == 64) return launch_hd20<64>(a, nwg, win, s);
+  if (CK == 128) return launch_hd20<128>(a, nwg, win, s);
+  if (CK == 256) return launch_hd20<256>(a, nwg, win, s);
+  return SWG_E_UNSUPPORTED;
+}
+#elif defined(RING_TU_192)
 int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, hipStream_t s) {
   const RingAttnArgs& a = *static_cast<const RingAttnArgs*>(args);
   // small windows (attention core on pre-normalised rows only): 4x4 = one MFMA tile per wave, 2x2 = four windows per tile
@@ -639,7 +673,10 @@ int launch_wattn_ring_c192(const void* args, int nwg, int win, bool fuse_proj, h
 // 6x6 / 8x8 windows: every form.  4x4 (one MFMA tile per wave) and 2x2 windows (four windows per tile): the attention
 // core on pre-normalised rows only.
 bool wattn_ring_supported(int C, int heads, int win, int res) {
-  if (!((C == 192 || C == 384) && heads * 32 == C && res % win == 0)) return false;
+  if (res % win) return false;
+  // head_dim 20 (the dim-60 networks): attention core with every head padded to a 32-slot group
+  if ((C == 60 || C == 120 || C == 240) && heads * 20 == C) return win == 8 || win == 4 || win == 2;
+  if (!((C == 192 || C == 384) && heads * 32 == C)) return false;
   if (win == 6 || win == 8) return true;
   return (win == 4 || win == 2) && !wattn_ring_fuses_proj(C) && wattn_ring_wants_xn(C);
 }
@@ -673,6 +710,8 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
                       int cond_stride, float* out, bf16* o, int ldo, hipStream_t s) {
   const int C = blk->C;
   if (!wattn_ring_supported(C, blk->heads, blk->win, blk->res) || !blk->attn_img) return SWG_E_UNSUPPORTED;
+  const bool hd20 = blk->heads * 20 == C;
+  if (hd20 && ldo < blk->heads * 32) return SWG_E_SHAPE;
   if (wattn_ring_fuses_proj(C) ? !out : (!o || ldo % 8)) return SWG_E_NULL;
   if (wattn_ring_wants_xn(C) && (!xn || ldxn % 8)) return SWG_E_NULL;
   const int nW = (blk->res / blk->win) * (blk->res / blk->win);
@@ -685,10 +724,12 @@ int launch_wattn_ring(const swg_block* blk, int B, const float* x, const bf16* x
   // algorithmic bytes per token and channel: fused projection: x in (4, shortcut) + out (4) [+ 2 for the pre-normalised
   // bf16 rows]; attention core only: normalised rows in (2) + o out (2).  Weights: one pass of the stream (2 B each).
   const double row_bytes = wattn_ring_fuses_proj(C) ? (xn ? 10.0 : 8.0) : 4.0;
-  SwgProfScope ps(C == 384 ? KID_WATTN_RING_384 : KID_WATTN_RING, gemm * T * C * C + 4.0 * T * (blk->win * blk->win) * C,
+  SwgProfScope ps(hd20 ? KID_WATTN_RING_HD20 : C == 384 ? KID_WATTN_RING_384 : KID_WATTN_RING, gemm * T * C * C + 4.0 * T * (blk->win * blk->win) * C,
                   row_bytes * T * C + gemm * C * C, s);
   int r;
-  if (blk->win == 4 || blk->win == 2) {
+  if (hd20) {
+    r = launch_wattn_ring_hd20(&a, nwg, round_up(C, 32), blk->win, s);
+  } else if (blk->win == 4 || blk->win == 2) {
     if (C == 192) r = launch_wattn_ring_c192(&a, nwg, blk->win, false, s);
     else r = blk->win == 4 ? launch_t<384, false, 5, 1, 5, true, 4>(a, nwg, s)
                            : launch_t<384, false, 5, 1, 5, true, 2, false, 4>(a, nwg, s);

@@ -276,6 +276,7 @@ RING192_FUSE_PROJ = os.environ.get("SWG_RING192_FUSE_PROJ", "0") == "1"
 # channel counts with the fused attention-tail + MLP kernel (csrc/mlp_stream.hip, PROJ form)
 PROJ_MLP_DIMS = (384,) if RING192_FUSE_PROJ else (384, 192)
 USE_FUSED_ATTN = True
+RING_HD20 = os.environ.get("SWG_RING_HD20", "1") == "1"   # A/B knob: fused attention core for head_dim 20
 RING_SMALL_WINDOWS = os.environ.get("SWG_RING_SMALL_WINDOWS", "1") == "1"   # A/B knob: 4x4 / 2x2 windows at C = 192 / 384
 
 
@@ -308,11 +309,23 @@ def wattn_ring_image(qkv_w: torch.Tensor, proj_w: torch.Tensor, heads: int, fuse
     the order the kernel stores o (slot h*32 + 8lg + e holds head dim pi(lg, e))."""
     qkv_w, proj_w = qkv_w.detach().float(), proj_w.detach().float()
     Cdim = proj_w.shape[0]
-    ks = Cdim // 32
     dev = qkv_w.device
+    hd = Cdim // heads
+    if hd != 32:
+        # head_dim 20: every head padded to a 32-slot group (slots hd..31 zero), input channels to the 32-deep k-step
+        assert not fuse_proj and hd < 32
+        ck = -(-Cdim // 32) * 32
+        q = torch.zeros(3, heads, 32, ck, device=dev)
+        q[:, :, :hd, :Cdim] = qkv_w.reshape(3, heads, hd, Cdim)
+        qkv_w = q.reshape(3 * heads * 32, ck)
+        pw = torch.zeros(Cdim, heads, 32, device=dev)
+        pw[:, :, :hd] = proj_w.reshape(Cdim, heads, hd)
+        proj_w = pw.reshape(Cdim, heads * 32)
+    co = heads * 32                       # q / k / v slot rows
+    ks = qkv_w.shape[1] // 32
     slabs = []
     for part in (2, 0, 1):  # V, Q, K
-        w = qkv_w[part * Cdim:(part + 1) * Cdim].reshape(heads, 2, 16, ks, 4, 8)   # [h, dt, i, ks, lg, e]
+        w = qkv_w[part * co:(part + 1) * co].reshape(heads, 2, 16, ks, 4, 8)       # [h, dt, i, ks, lg, e]
         slabs.append(w.permute(0, 3, 1, 4, 2, 5).reshape(heads, -1))               # [h, (ks, dt, lg, i, e)]
     wp = proj_w.reshape(Cdim, heads, 32)[..., _pi(dev)]                             # [c, h, slot]
     if fuse_proj:
@@ -334,6 +347,10 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
             and blk.dim // blk.num_heads == 32 and blk.input_resolution[0] % blk.window_size == 0):
         aimg = _ptr(keep.image(wattn_ring_image, (blk.attn.qkv.weight, blk.attn.proj.weight), blk.num_heads,
                                RING_ATTN_FUSED_PROJ[blk.dim]))
+    elif (USE_FUSED_ATTN and RING_HD20 and blk.dim in (60, 120, 240) and blk.num_heads * 20 == blk.dim
+            and blk.window_size in (2, 4, 8) and blk.input_resolution[0] % blk.window_size == 0):
+        # head_dim 20 (the dim-60 networks): attention core with 32-slot head groups (csrc/wattn_ring.hip HD = 20)
+        aimg = _ptr(keep.image(wattn_ring_image, (blk.attn.qkv.weight, blk.attn.proj.weight), blk.num_heads, False))
     pimg = None
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
         img = _ptr(keep.image(mlp_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight)))

@@ -138,6 +138,14 @@ SMALL_WINDOW_CASES = {
     "r8_w4_s2_c192_tail": dict(C=192, res=8, heads=6, window=4, shift=2, B=200, seed=86, tail=True),
     "r4_w4_s0_c384_tail": dict(C=384, res=4, heads=12, window=4, shift=0, B=800, seed=87, tail=True),
     "r4_w2_s1_c384_tail": dict(C=384, res=4, heads=12, window=2, shift=1, B=801, seed=88, tail=True),
+    # head_dim 20 (the dim-60 networks): every head padded to a 32-slot group in the weight image
+    "r8_w24_c60": dict(C=60, res=8, heads=3, window=24, shift=0, B=5, seed=91, tail=False),        # clamp -> w=8
+    "r16_w8_s4_c60": dict(C=60, res=16, heads=3, window=8, shift=4, B=2, seed=92, tail=False),
+    "r16_w4_s2_c60": dict(C=60, res=16, heads=3, window=4, shift=2, B=2, seed=93, tail=False),
+    "r8_w4_s2_c120": dict(C=120, res=8, heads=6, window=4, shift=2, B=3, seed=94, tail=False),
+    "r4_w4_s0_c240": dict(C=240, res=4, heads=12, window=4, shift=0, B=5, seed=95, tail=False),
+    "r4_w2_s1_c240": dict(C=240, res=4, heads=12, window=2, shift=1, B=3, seed=96, tail=False),
+    "r2_w24_c240_b7": dict(C=240, res=2, heads=12, window=24, shift=0, B=7, seed=97, tail=False),  # clamp -> w=2
 }
 
 
@@ -155,7 +163,8 @@ def test_small_window_blocks(S, name):
         out = blk(x.to(DEV), emb.to(DEV))
         torch.cuda.synchronize()
         ran = set(prof.read())
-    assert f"k_wattn_ring<{c['C']}>" in ran and "k_wattn_core" not in ran, ran
+    ring = "k_wattn_ring<hd20>" if c["C"] % 60 == 0 else f"k_wattn_ring<{c['C']}>"
+    assert ring in ran and "k_wattn_core" not in ran, ran
     assert (f"k_mlp_stream<{c['C']},proj>" in ran) == c["tail"], ran
     ref = O.swin_block(x, emb, full, "blk", c["res"], c["heads"], c["window"], c["shift"])
     rel_close(out, ref)
