@@ -32,8 +32,13 @@ struct MlpArgs {
 // 16-byte slot swizzle of a 64-byte LDS row (4 slots): conflict-free for ds_read_b128 fragment reads
 __device__ __forceinline__ int slot_swz(int row, int ch) { return ch ^ ((-(row >> 2)) & 3); }
 
-template <int C, bool KEEPX>
+// CT < C (the dim-60 networks: CT = 60 / 120 true channels in C = 64 / 128 operand slots): rows, LayerNorm constants and
+// biases hold CT entries; the slots CT..C-1 are loaded as zero, stay out of the variance, and are not stored.  The
+// weight image is zero-padded to [4C, C] / [C, 4C] (engine.py), so padded hidden features are gelu(0) = 0.
+template <int C, bool KEEPX, int CT = C>
 __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
+  static_assert(CT % 4 == 0 && CT <= C && C - CT < 32, "padding lives in the last k-step, in whole float4 groups");
+  constexpr bool PAD = CT != C;
   constexpr int KS = C / 32;       // k-steps of fc1
   constexpr int NT = C / 16;       // output feature tiles of fc2
   constexpr int NCH = 4 * C / HC;  // hidden chunks
@@ -58,7 +63,7 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
   };
   stage(0, 0);
   float* sb1 = reinterpret_cast<float*>(smem + 2 * CHUNK_BYTES);  // fc1 bias [4C] (read every chunk)
-  for (int i = tid; i < 4 * C; i += 256) sb1[i] = a.b1[i];
+  for (int i = tid; i < 4 * C; i += 256) sb1[i] = (!PAD || i < 4 * CT) ? a.b1[i] : 0.f;
 
   // ---- load the wave's 32 token rows in operand layout, LayerNorm2 in registers ----
   bf16x8 xa[2][KS];
@@ -66,33 +71,40 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
-    const float* row = a.x + (size_t)tok * C;
+    const float* row = a.x + (size_t)tok * CT;
     float v[KS][8];
     float s = 0.f;
+    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+    // float4 group hh of k-step ks holds channels 32ks + 8lg + 4hh ..+3: real below CT (only the last k-step pads)
+    auto real = [&](int ks, int hh) { return !PAD || ks < KS - 1 || 32 * ks + 8 * lg + 4 * hh < CT; };
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const float4 p0 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg);
-      const float4 p1 = *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg + 4);
+      const float4 p0 = real(ks, 0) ? *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg) : z4;
+      const float4 p1 = real(ks, 1) ? *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg + 4) : z4;
       v[ks][0] = p0.x; v[ks][1] = p0.y; v[ks][2] = p0.z; v[ks][3] = p0.w;
       v[ks][4] = p1.x; v[ks][5] = p1.y; v[ks][6] = p1.z; v[ks][7] = p1.w;
 #pragma unroll
       for (int j = 0; j < 8; ++j) s += v[ks][j];
     }
     s = rows_sum(s);
-    const float mean = s * (1.0f / C);
+    const float mean = s * (1.0f / CT);
     float q = 0.f;
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks)
 #pragma unroll
-      for (int j = 0; j < 8; ++j) { const float d = v[ks][j] - mean; q += d * d; }
+      for (int j = 0; j < 8; ++j) {
+        const float d = real(ks, j >> 2) ? v[ks][j] - mean : 0.f;
+        q += d * d;
+      }
     q = rows_sum(q);
-    const float rstd = ln_rstd(q * (1.0f / C));
+    const float rstd = ln_rstd(q * (1.0f / CT));
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const float4 g0 = *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg);
-      const float4 g1 = *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg + 4);
-      const float4 b0 = *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg);
-      const float4 b1 = *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg + 4);
+      // padded slots: g = b = 0, so the operand is 0
+      const float4 g0 = real(ks, 0) ? *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg) : z4;
+      const float4 g1 = real(ks, 1) ? *reinterpret_cast<const float4*>(a.g + 32 * ks + 8 * lg + 4) : z4;
+      const float4 b0 = real(ks, 0) ? *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg) : z4;
+      const float4 b1 = real(ks, 1) ? *reinterpret_cast<const float4*>(a.b + 32 * ks + 8 * lg + 4) : z4;
       const float gg[8] = {g0.x, g0.y, g0.z, g0.w, g1.x, g1.y, g1.z, g1.w};
       const float bb[8] = {b0.x, b0.y, b0.z, b0.w, b1.x, b1.y, b1.z, b1.w};
       bf16x8 f;
@@ -200,35 +212,40 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
     for (int nt = 0; nt < NT; ++nt) {
       const int ks = nt >> 1, hh = nt & 1;
       const int c = 32 * ks + 8 * lg + 4 * hh;
+      if (PAD && ks == KS - 1 && c >= CT) continue;
       const float4 bb = *reinterpret_cast<const float4*>(a.b2 + c);
       float4 r4;
       if (KEEPX) r4 = make_float4(xr[mt][ks][4 * hh], xr[mt][ks][4 * hh + 1], xr[mt][ks][4 * hh + 2], xr[mt][ks][4 * hh + 3]);
-      else r4 = *reinterpret_cast<const float4*>(a.x + (size_t)tok * C + c);
+      else r4 = *reinterpret_cast<const float4*>(a.x + (size_t)tok * CT + c);
       float4 o;
       o.x = acc[nt][mt][0] + bb.x + r4.x;
       o.y = acc[nt][mt][1] + bb.y + r4.y;
       o.z = acc[nt][mt][2] + bb.z + r4.z;
       o.w = acc[nt][mt][3] + bb.w + r4.w;
-      *reinterpret_cast<float4*>(a.out + (size_t)tok * C + c) = o;
+      *reinterpret_cast<float4*>(a.out + (size_t)tok * CT + c) = o;
     }
   }
 }
 
 }  // namespace
 
-bool mlp_fused_supported(int C) { return C == 96; }
+// C = 96; C = 60 / 120 (head_dim-20 networks) on zero-padded 64 / 128-slot operands
+bool mlp_fused_supported(int C) { return C == 96 || C == 60 || C == 120; }
 
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                      const float* g, const float* b, hipStream_t s) {
   if (!mlp_fused_supported(C)) return SWG_E_UNSUPPORTED;
   if (T <= 0) return 0;
   MlpArgs a = {x, out, img, b1, b2, g, b, T};
-  const size_t lds = (size_t)2 * (2 * HC * C) * 2 + (size_t)4 * C * sizeof(float);
+  const int Cs = round_up(C, 32);   // operand slots
+  const size_t lds = (size_t)2 * (2 * HC * Cs) * 2 + (size_t)4 * Cs * sizeof(float);
   SwgProfScope ps(KID_FUSED_MLP, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);
   dim3 grid(cdiv(T, 128)), block(256);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
   if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_fused<192, false>, (int)(2 * (2 * HC * 192) * 2 + 4 * 192 * 4))) return e;
   if (C == 96) hipLaunchKernelGGL((k_mlp_fused<96, true>), grid, block, lds, s, a);
+  else if (C == 60) hipLaunchKernelGGL((k_mlp_fused<64, true, 60>), grid, block, lds, s, a);
+  else if (C == 120) hipLaunchKernelGGL((k_mlp_fused<128, false, 120>), grid, block, lds, s, a);
   else hipLaunchKernelGGL((k_mlp_fused<192, false>), grid, block, lds, s, a);
   SWG_LAUNCH_CHECK();
   return 0;

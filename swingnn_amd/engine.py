@@ -181,7 +181,7 @@ class RefreshTable:
                                               self.c1.data_ptr(), self.n_chunks, stream_ptr()), "swg_refresh_derived")
 
 
-FUSED_MLP_DIMS = (96,)
+FUSED_MLP_DIMS = (96, 60, 120) if os.environ.get("SWG_MLP_FUSED_PAD", "1") == "1" else (96,)   # 60 / 120: A/B knob
 USE_FUSED_MLP = True
 
 
@@ -201,6 +201,13 @@ def mlp_image(w1: torch.Tensor, w2: torch.Tensor, dtype=torch.bfloat16) -> torch
     the k order the fc1 accumulators imply (and the fc2 rows permuted, see below): element e of chunk ch is hidden 32*s + (4ch+e if e<4 else 16+4ch+e-4)."""
     w1, w2 = w1.detach().float(), w2.detach().float()
     H, Cdim = w1.shape
+    if Cdim % 32:   # C = 60 / 120: zero-padded to 64 / 128 channel slots and 4 x that many hidden features
+        cs = -(-Cdim // 32) * 32
+        p1 = torch.zeros(4 * cs, cs, device=w1.device)
+        p1[:H, :Cdim] = w1
+        p2 = torch.zeros(cs, 4 * cs, device=w1.device)
+        p2[:Cdim, :H] = w2
+        w1, w2, H, Cdim = p1, p2, 4 * cs, cs
     nch, ks = H // 64, Cdim // 32
     a = w1.reshape(nch, 64, ks, 4, 8).permute(0, 2, 1, 3, 4)              # [hc, s, r, ch, e]
     a = _slot_swizzle(a.contiguous()).reshape(nch, -1)

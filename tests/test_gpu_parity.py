@@ -93,6 +93,9 @@ def test_swin_block(S, golden, name):
 EXTRA_BLOCK_CASES = {
     "r12_w6_s3_c384": dict(C=384, res=12, heads=12, window=6, shift=3, B=3, seed=71),
     "r12_w6_s0_c384": dict(C=384, res=12, heads=12, window=6, shift=0, B=1, seed=72),
+    # k_mlp_fused on zero-padded operand slots (C = 60 / 120 in 64 / 128), token counts that are no multiple of 128
+    "r8_w8_s0_c60": dict(C=60, res=8, heads=3, window=8, shift=0, B=5, seed=73),
+    "r4_w4_s0_c120": dict(C=120, res=4, heads=6, window=4, shift=0, B=9, seed=74),
 }
 
 
