@@ -638,7 +638,11 @@ PASS_COUNT = 0  # network passes launched through network_pass (reported by benc
 # library's per-kernel profiler is on, the SAME part-batch launches are issued one after the other on the caller's
 # stream (overlapped kernels would be timed against each other): what is timed is what the product path launches.
 SPLIT_STREAMS = int(os.environ.get("SWG_SPLIT_STREAMS", "2"))   # tuning knob for scripts/, not an API
-SPLIT_MIN_WORK = 8_000_000   # B * N * N below which a pass stays on one stream
+# B * N * N below which a pass stays on one stream.  Measured (profiles/r03_split_sweep.txt, ms per pass, one stream ->
+# two): grid B = 44 3.04 -> 2.88, B = 14 1.72 -> 1.74; DD B = 28 3.41 -> 3.28, B = 8 1.95 -> 1.99; the small-graph
+# networks (N = 24, 14 blocks: many short launches) gain from 1 M: ego-small B = 2048 2.48 -> 2.32, B = 1024 1.86 -> 1.96.
+SPLIT_MIN_WORK = int(os.environ.get("SWG_SPLIT_MIN_WORK", "4000000"))
+SPLIT_SMALL_N, SPLIT_SMALL_DIV = 64, 4    # graphs of N <= 64 nodes: a quarter of that bound
 _SIDE = {}
 _PROFILING = False           # set by prof.profiled()
 
@@ -650,7 +654,7 @@ def launch_batch(B: int, N: int, cache=None) -> int:
     16384 of its gate, and the stage fell back to the GEMM route) is refused: the part-batch must take the same
     kernels as the whole batch (swg_fused_op_count)."""
     parts = SPLIT_STREAMS
-    if parts < 2 or B % parts or B * N * N < SPLIT_MIN_WORK:
+    if parts < 2 or B % parts or B * N * N < (SPLIT_MIN_WORK // SPLIT_SMALL_DIV if N <= SPLIT_SMALL_N else SPLIT_MIN_WORK):
         return B
     if cache is not None and cache.fused_ops(B // parts) != cache.fused_ops(B):
         return B
