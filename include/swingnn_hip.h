@@ -54,9 +54,11 @@ typedef struct swg_block {
    * per-64-hidden-chunk LDS image in swizzled MFMA fragment order (swingnn_amd/engine.py mlp_image).
    * NULL -> the GEMM-based path is used. */
   const void* mlp_img;
-  /* optional derived cache for the fused window-attention kernel (C = 96 or 192, head_dim 32, 6x6
-   * windows): per head, the Wq/Wk/Wv rows and the Wproj columns as an LDS image in swizzled MFMA fragment
-   * order (swingnn_amd/engine.py wattn_image).  NULL -> the 4-kernel path is used. */
+  /* optional derived cache for the fused window-attention kernels (swingnn_amd/engine.py wattn_ring_image): per head
+   * the Wv / Wq / Wk rows as 1-KiB MFMA fragments, then -- C = 96: the Wproj columns in the same stream; C = 192 / 384
+   * (head_dim 32, windows 2 / 4 / 6 / 8) and C = 60 / 120 / 240 (head_dim 20, windows 2 / 4 / 8; every head padded to a
+   * 32-slot group, channels to a multiple of 32) -- the slot-permuted Wproj [C, heads * 32] behind the stream for the
+   * projection GEMM / the fused tail.  NULL -> the 4-kernel path (qkv GEMM, k_wattn_core, projection GEMM) is used. */
   const void* attn_img;
   /* optional derived cache for the fused attention-tail + MLP kernel (C = 384): the projection weight as MFMA
    * fragments (k-step major, rho-ordered out tiles, input columns in the slot order of the attention output)
