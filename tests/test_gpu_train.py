@@ -215,6 +215,10 @@ def test_derived_operand_refresh_equals_rebuild(golden_meta, golden_nodeadj, kin
         assert m0 == m1 and torch.equal(d0, d1), m0
     for name in ("_aw", "_ab", "_pe_w"):
         assert torch.equal(getattr(cache, name), getattr(fresh, name)), name
+    # relative-position bias tiles of the 6x6-window ring kernels (swg_rpb_tiles): rebuilt by the refresh as well
+    assert len(cache.keep.rpb_tiles) == len(fresh.keep.rpb_tiles) and (len(cache.keep.rpb_tiles) >= 4) == (kind == "swingnn")
+    for (_, _, _, t0), (_, _, _, t1) in zip(cache.keep.rpb_tiles, fresh.keep.rpb_tiles):
+        assert torch.equal(t0, t1)
     if kind == "swingnn":
         assert torch.allclose(cache._ro_w, fresh._ro_w, rtol=1e-6, atol=1e-9) and abs(cache.net.ro_b - fresh.net.ro_b) < 1e-6
         assert torch.equal(tcache.ro_wb, tfresh.ro_wb)
