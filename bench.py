@@ -385,10 +385,13 @@ def main():
             dist.barrier()
             torch.cuda.synchronize()
 
-    last = {}
+    last = {"passes": []}
+    from swingnn_amd import engine as _E
 
     def one_step():
+        n0 = _E.PASS_COUNT
         last["out"] = sampler.sample(model, flags)
+        last["passes"].append(_E.PASS_COUNT - n0)
 
     per_rank = []
     with torch.no_grad():
@@ -396,7 +399,7 @@ def main():
                          per_rank=per_rank)
     out = last["out"]
     assert torch.isfinite(out).all()
-    from swingnn_amd import engine as _E
+    timed_passes = last["passes"][args.warmup:]
     # ---- extra, NOT the headline value: the same workload with EDMSampler.reuse_passes (network passes of a Heun step
     # that repeat an evaluation at the same (x_hat, sigma_hat) are reused; bit-identical samples) ----
     reuse = None
@@ -427,6 +430,7 @@ def main():
         sampler.precompute_conditioning = True
         with torch.no_grad():
             barrier()
+            n3 = _E.PASS_COUNT
             t0 = time.perf_counter()
             sampler.sample(model, flags)
             barrier()
@@ -436,7 +440,7 @@ def main():
             t = torch.tensor([dt3], device=dev, dtype=torch.float64)
             dist.all_reduce(t, op=dist.ReduceOp.MAX)
             dt3 = float(t.item())
-        precond_extra = dict(value=args.batch * world / dt3, unit="graphs/s",
+        precond_extra = dict(value=args.batch * world / dt3, unit="graphs/s", network_passes_per_sample=_E.PASS_COUNT - n3,
                              note="EDMSampler.precompute_conditioning=True (opt-in, off in the headline value): one "
                                   "swg_cond_table call per sample() replaces the noise-embedding launches at the head "
                                   "of every pass; samples bit-identical (tests/test_gpu_parity.py::"
@@ -470,6 +474,9 @@ def main():
                                    f"dim-{cfg['embed_dim']}, depths {cfg['depths']}, window {cfg['window_size']}, "
                                    f"{args.num_steps} steps, self_cond, random-init weights",
                        "batch_per_gpu": args.batch, "global_batch": args.batch * world, "graphs_per_launch": lb,
+                       # 511 model calls, each one or two passes by the reference's numpy coin (precond.py:40): the count
+                       # varies by +-1.5 % between sample() calls, and so does the time (scripts/exp_sample_drift.py)
+                       "network_passes_per_step": timed_passes,
                        "launch": "HIP-graph replay per network pass" if args.graphs else "eager kernel launches",
                        "parallelism": f"independent replicas x{world} (batch-sharded, no collective)"},
             "roofline": roof,
