@@ -192,6 +192,45 @@ def test_small_window_blocks(S, name):
     rel_close(out2, ref16r, **BLOCK_BF16_BARS)
 
 
+def _sweep_cases():
+    """Seeded sweep over the block geometries the fused kernels claim: (C, heads) x window x resolution (1-3 windows
+    per side) x shift x batch (ragged workgroup / pack / tile counts)."""
+    rng = np.random.default_rng(20260311)
+    out = []
+    for C, heads, wins in ((96, 3, (4, 6, 8)), (192, 6, (2, 4, 6, 8)), (384, 12, (2, 4, 6, 8)),
+                           (60, 3, (2, 4, 8)), (120, 6, (2, 4, 8)), (240, 12, (2, 4, 8))):
+        for w in wins:
+            for _ in range(2):
+                nw = int(rng.integers(1, 4))
+                res = w * nw
+                shift = int(rng.integers(1, w)) if nw > 1 and rng.random() < 0.7 else 0
+                B = int(rng.integers(1, 8))
+                out.append(dict(C=C, heads=heads, window=w, res=res, shift=shift, B=B, seed=int(rng.integers(1, 1 << 20))))
+    return out
+
+
+SWEEP = _sweep_cases()
+
+
+@pytest.mark.parametrize("c", SWEEP, ids=[f"c{c['C']}_w{c['window']}_r{c['res']}_s{c['shift']}_b{c['B']}" for c in SWEEP])
+def test_block_geometry_sweep(S, c):
+    w, s = O.eff_window(c["res"], c["window"], c["shift"])
+    full = H.block_state(c["C"], c["heads"], w, c["seed"])
+    blk = load(S.SwinTransformerBlock(c["C"], 512, (c["res"],) * 2, c["heads"], c["window"], c["shift"]),
+               strip(full, "blk."))
+    x = filler.uniform("x", (c["B"], c["res"] ** 2, c["C"]), c["seed"])
+    emb = filler.uniform("emb", (c["B"], 512), c["seed"])
+    out = blk(x.to(DEV), emb.to(DEV))
+    with O.bf16_operands():
+        ref16 = O.swin_block(x, emb, full, "blk", c["res"], c["heads"], c["window"], c["shift"])
+    scale = float(ref16.abs().max())
+    err = (out.cpu() - ref16).abs()
+    print(f"sweep {c}: max {float(err.max()) / scale:.2e} mean {float(err.mean()) / scale:.2e}")
+    # measured: max 4.6e-5 .. 2.8e-3, mean 3.5e-6 .. 1.5e-4 of the output scale; the one-graph cases (4 - 64 tokens)
+    # reach a mean of 3.6e-4 (a few rounding flips in a few hundred values), hence the mean bar of 5e-4 here
+    rel_close(out, ref16, max_rel=BLOCK_BF16_BARS["max_rel"], mean_rel=5e-4)
+
+
 def test_block_attention_half_only(S):
     """swg_wattn_fwd alone (no MLP) against the oracle's attention half, shifted 6x6 windows."""
     import ctypes as C
