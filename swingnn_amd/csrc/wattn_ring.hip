@@ -114,6 +114,8 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   const bool need_mask = __builtin_amdgcn_readfirstlane(
       (int)(a.shift > 0 && (PACK > 1 || wy == nwx - 1 || wx == nwx - 1))) != 0;
   const int nunits = UH * a.heads;
+  // gridDim.y head groups (launches with few windows: each workgroup streams only its heads' part of the weights)
+  const int hpg = a.heads / (int)gridDim.y, h0 = (int)blockIdx.y * hpg;
 #ifdef SWG_STAMPS
   const bool dbg = (blockIdx.x == 8 || blockIdx.x == gridDim.x / 2) && (wave == 0 || wave == 2);
   const int dbgslot = (blockIdx.x == 8 ? 0 : 2) + (wave == 0 ? 0 : 1);
@@ -269,7 +271,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 #pragma unroll
   for (int u = 0; u < NBUF - 1; ++u)
 #pragma unroll
-    for (int i = 0; i < PIECES; ++i) STAGE_PIECE(min(u, nunits - 1), u * UNIT_BYTES, i);
+    for (int i = 0; i < PIECES; ++i) STAGE_PIECE(min(h0 * UH + u, nunits - 1), u * UNIT_BYTES, i);
   int qrel[NTM], krel[NTM][4], rids[NTM];
   int boff[BIAS_REGS ? NTM : 1][BIAS_REGS ? NTM : 1][4];
   const float kpad = (4 * lg < REM) ? 0.f : -3.0e38f;  // last key tile: keys 4*lg + r exist only below REM
@@ -306,7 +308,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   bf16x8 fr[AHEAD + 1];
 #pragma unroll
   for (int p = 0; p < AHEAD; ++p) fr[p] = *reinterpret_cast<const bf16x8*>(smem + lane * 16 + p * 1024);
-  int unit = 0;      // stream unit of the head's first fragment
+  int unit = h0 * UH;  // stream unit of the head's first fragment
   int slot = 0;      // its ring slot (unit % NBUF)
 
   // One issue group: fragment G of the head (compile-time G).  At a unit start the barrier is taken for the NEXT
@@ -335,7 +337,7 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
   }
 
 #pragma nounroll
-  for (int h = 0; h < a.heads; ++h) {
+  for (int h = h0; h < h0 + hpg; ++h) {
     // ring slots of the head's units and of the next head's first unit (the fragment prefetch runs AHEAD into it)
     unsigned uoff[UH + 1];
     const char* ub[UH + 1];
@@ -620,11 +622,16 @@ __global__ __launch_bounds__(256, LB) void k_wattn_ring(RingAttnArgs a) {
 template <int C, bool FUSE_PROJ, int NBUF, int LB, int AHEAD, bool PRE_LN, int WIN, bool BT = false, int PACK = 1, int HD = 32>
 int launch_t(const RingAttnArgs& a, int nwg, hipStream_t s) {
   constexpr int UNIT = ring_unit((FUSE_PROJ ? 4 : 3) * 2 * (C / 32));
+  // Few windows (the deep stages of the small-graph networks): split the heads over gridDim.y so that the launch has
+  // up to 256 workgroups, each streaming a fraction of the weights (attention-core instances only: o is per head).
+  int hg = 1;
+  if (!FUSE_PROJ)
+    while (nwg * hg * 2 <= 256 && a.heads % (hg * 2) == 0 && a.heads / (hg * 2) >= 3) hg *= 2;
   const int CO = HD == 32 ? C : a.heads * 32;
   const size_t lds = (size_t)NBUF * UNIT * 1024 + (size_t)(4 * CO + ((2 * WIN - 1) * (2 * WIN - 1) + 1) * a.heads) * sizeof(float);
   static std::atomic<uint64_t> lds_ok{0};  // dynamic LDS above 64 KiB needs an explicit opt-in, per device
   if (int e = ensure_dyn_lds(lds_ok, (const void*)k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK, HD>, (int)((int)lds))) return e;
-  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK, HD>), dim3(nwg), dim3(256), lds, s, a);
+  hipLaunchKernelGGL((k_wattn_ring<C, FUSE_PROJ, NBUF, LB, AHEAD, PRE_LN, WIN, BT, PACK, HD>), dim3(nwg, hg), dim3(256), lds, s, a);
   return 0;
 }
 
