@@ -128,6 +128,13 @@ bool fused_tail_ok(const swg_block* blk, int B) {
          (size_t)B * L >= fused_gate(kFusedGate) && wattn_ring_supported(C, blk->heads, blk->win, blk->res) &&
          !wattn_ring_fuses_proj(C);
 }
+// head_dim-20 blocks (C = 60 / 120): attention core (k_wattn_ring<hd20>) + k_mlp_fused PROJ form; no token gate (both
+// kernels take 64 / 128 tokens per workgroup)
+static bool fused_tail_hd20_ok(const swg_block* blk) {
+  const int C = blk->C;
+  return blk->proj_mlp_img && blk->attn_img && blk->mlp_img && mlp_fused_proj_supported(C) && blk->heads * 20 == C &&
+         wattn_ring_supported(C, blk->heads, blk->win, blk->res);
+}
 static bool mlp_stream_ok(const swg_block* blk, int B) {
   const int C = blk->C;
   const size_t T = (size_t)B * blk->res * blk->res;
@@ -158,6 +165,19 @@ int block_impl(const swg_block* blk, int B, const float* x_in, const float* cond
     if ((r = launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, nullptr, o, Cp, s))) return r;
     return launch_mlp_stream_proj(C, T, L, x_in, o, Cp, cond, cond_stride, blk->cond_off, blk->proj.b, x_out,
                                   (const bf16*)blk->proj_mlp_img, blk->fc1.b, blk->fc2.b, blk->ln2.g, blk->ln2.b, s);
+  }
+  if (fused_tail_hd20_ok(blk)) {
+    const int CO = blk->heads * 32;
+    Carver cv(ws, ws_bytes);
+    bf16* xn = cv.take<bf16>((size_t)T * Cp);
+    bf16* o = cv.take<bf16>((size_t)T * CO);
+    if (!cv.ok) return SWG_E_WORKSPACE;
+    if ((r = launch_cond_ln(x_in, T, C, L, cond, cond_stride, blk->cond_off, blk->ln1.g, blk->ln1.b, nullptr, xn, Cp, s)))
+      return r;
+    if ((r = launch_wattn_ring(blk, B, x_in, xn, Cp, cond, cond_stride, nullptr, o, CO, s))) return r;
+    return launch_mlp_fused_proj(C, T, L, x_in, o, CO, cond, cond_stride, blk->cond_off, blk->proj.b, x_out,
+                                 (const bf16*)blk->proj_mlp_img, (const bf16*)blk->mlp_img, blk->fc1.b, blk->fc2.b,
+                                 blk->ln2.g, blk->ln2.b, s);
   }
   if ((r = wattn_impl(blk, B, x_in, cond, cond_stride, x_out, ws, ws_bytes, s))) return r;
   return mlp_impl(blk, B, x_out, x_out, ws, ws_bytes, s);
@@ -453,7 +473,7 @@ int32_t swg_fused_op_count(const swg_net* net, int32_t B) {
     if (ly.up && expand_fused_ok(ly.up, B)) ++n;
     for (int j = 0; j < ly.n_blocks; ++j) {
       const swg_block* b = &ly.blocks[j];
-      if (fused_tail_ok(b, B)) n += 2;
+      if (fused_tail_ok(b, B) || fused_tail_hd20_ok(b)) n += 2;
       else if (mlp_stream_ok(b, B)) ++n;
     }
     if (ly.down && merge_fused_ok(ly.down, B)) ++n;

@@ -358,6 +358,11 @@ int launch_expand_fused(int Cin, int B, int res, const float* x, const float* sk
                         float* out, hipStream_t s);
 // mlp_stream.hip : the same for the wide stages (C = 384), LDS ring + skewed GELU pipeline, fragment-order image
 bool mlp_stream_supported(int C);
+// PROJ form of k_mlp_fused (head_dim-20 blocks, C = 60 / 120): attention tail + MLP half in one pass
+bool mlp_fused_proj_supported(int C);
+int launch_mlp_fused_proj(int C, int T, int L, const float* x_in, const bf16* o, int ldo, const float* cond, int cond_stride,
+                          int cond_off, const float* proj_b, float* out, const bf16* pimg, const bf16* img, const float* b1,
+                          const float* b2, const float* g, const float* b, hipStream_t s);
 bool mlp_stream_proj_supported(int C);
 int launch_mlp_stream_proj(int C, int T, int L, const float* x_in, const bf16* o, int ldo, const float* cond, int cond_stride,
                            int cond_off, const float* proj_b, float* out, const bf16* img, const float* b1,

@@ -27,6 +27,13 @@ struct MlpArgs {
   const float* g;    // LN2 weight
   const float* b;    // LN2 bias
   int T;
+  // PROJ form only (head_dim-20 blocks: attention tail folded in front of the MLP)
+  const bf16* o;      // attention output [T, ldo], 32-slot head groups as k_wattn_ring<hd20> stores them
+  int ldo;
+  const bf16* pimg;   // projection weight as fragments (engine.py proj_frag_image)
+  const float* pb;    // proj bias [CT]
+  const float* cond;  // conditioning rows [B, cond_stride]; this block's (scale | shift) at cond_off
+  int cond_stride, cond_off, L;
 };
 
 // 16-byte slot swizzle of a 64-byte LDS row (4 slots): conflict-free for ds_read_b128 fragment reads
@@ -35,10 +42,17 @@ __device__ __forceinline__ int slot_swz(int row, int ch) { return ch ^ ((-(row >
 // CT < C (the dim-60 networks: CT = 60 / 120 true channels in C = 64 / 128 operand slots): rows, LayerNorm constants and
 // biases hold CT entries; the slots CT..C-1 are loaded as zero, stay out of the variance, and are not stored.  The
 // weight image is zero-padded to [4C, C] / [C, 4C] (engine.py), so padded hidden features are gelu(0) = 0.
-template <int C, bool KEEPX, int CT = C>
+// PROJ (C = 64 / 128 with CT = 60 / 120, head_dim 20): the kernel starts from the block INPUT x and the attention output
+// o: the fc2 accumulators start as shortcut + proj bias (the shortcut silu(shift + x (1 + scale)) recomputed, :238-242),
+// KO = CT / 20 k-steps of Wproj fragments read straight from global memory (12 / 48 KiB, L2-resident) accumulate
+// o Wproj^T into them, LayerNorm2 reads the accumulators, and they go on as residual + fc2 bias: the projection GEMM
+// launch and the round trip of x through memory go.
+template <int C, bool KEEPX, int CT = C, bool PROJ = false>
 __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
   static_assert(CT % 4 == 0 && CT <= C && C - CT < 32, "padding lives in the last k-step, in whole float4 groups");
+  static_assert(!PROJ || (CT % 20 == 0 && !KEEPX), "PROJ: head_dim 20, residual in the accumulators");
   constexpr bool PAD = CT != C;
+  constexpr int KO = PROJ ? CT / 20 : 1;   // 32-slot head groups of o
   constexpr int KS = C / 32;       // k-steps of fc1
   constexpr int NT = C / 16;       // output feature tiles of fc2
   constexpr int NCH = 4 * C / HC;  // hidden chunks
@@ -68,19 +82,71 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
   // ---- load the wave's 32 token rows in operand layout, LayerNorm2 in registers ----
   bf16x8 xa[2][KS];
   float xr[KEEPX ? 2 : 1][KEEPX ? KS : 1][8];  // fp32 rows kept for the residual add (KEEPX)
+  f32x4 acc[NT][2];
+  const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
+  // float4 group hh of k-step ks holds channels 32ks + 8lg + 4hh ..+3: real below CT (only the last k-step pads)
+  auto real = [&](int ks, int hh) { return !PAD || ks < KS - 1 || 32 * ks + 8 * lg + 4 * hh < CT; };
+  if (PROJ) {
+    bf16x8 oa[2][KO];
+#pragma unroll
+    for (int mt = 0; mt < 2; ++mt) {
+      const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
+      const float* row = a.x + (size_t)tok * CT;
+      const float* crow = a.cond + (size_t)(tok / a.L) * a.cond_stride + a.cond_off;
+#pragma unroll
+      for (int ks = 0; ks < KS; ++ks)
+#pragma unroll
+        for (int hh = 0; hh < 2; ++hh) {
+          const int c = 32 * ks + 8 * lg + 4 * hh;
+          f32x4 r = {0.f, 0.f, 0.f, 0.f};
+          if (real(ks, hh)) {
+            const f32x4 xv = *reinterpret_cast<const f32x4*>(row + c);
+            const f32x4 sc = *reinterpret_cast<const f32x4*>(crow + c);
+            const f32x4 sh = *reinterpret_cast<const f32x4*>(crow + CT + c);
+            const f32x4 pb = *reinterpret_cast<const f32x4*>(a.pb + c);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) r[e] = silu_f(sh[e] + xv[e] * (sc[e] + 1.f)) + pb[e];
+          }
+          acc[2 * ks + hh][mt] = r;
+          if (hh) __builtin_amdgcn_sched_barrier(0);   // register peak: one k-step's loads hoisted at most
+        }
+      const bf16* orow = a.o + (size_t)tok * a.ldo + 8 * lg;
+#pragma unroll
+      for (int ko = 0; ko < KO; ++ko) oa[mt][PROJ ? ko : 0] = *reinterpret_cast<const bf16x8*>(orow + 32 * ko);
+    }
+    // acc^T += Wproj o^T: fragment (ko, nt), k-step major, rows in rho order, columns in o's slot order
+    const bf16* pf = a.pimg + lane * 8;
+#pragma unroll
+    for (int f = 0; f < KO * NT; ++f) {
+      const bf16x8 w = *reinterpret_cast<const bf16x8*>(pf + f * 512);
+      const int ko = f / NT, nt = f % NT;
+      acc[nt][0] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, oa[0][PROJ ? ko : 0], acc[nt][0], 0, 0, 0);
+      acc[nt][1] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(w, oa[1][PROJ ? ko : 0], acc[nt][1], 0, 0, 0);
+      if ((f & 7) == 7) __builtin_amdgcn_sched_barrier(0);   // register peak: at most eight fragment loads in flight
+    }
+  }
 #pragma unroll
   for (int mt = 0; mt < 2; ++mt) {
     const int tok = min(tok0 + mt * 16 + l15, a.T - 1);
     const float* row = a.x + (size_t)tok * CT;
     float v[KS][8];
     float s = 0.f;
-    const float4 z4 = make_float4(0.f, 0.f, 0.f, 0.f);
-    // float4 group hh of k-step ks holds channels 32ks + 8lg + 4hh ..+3: real below CT (only the last k-step pads)
-    auto real = [&](int ks, int hh) { return !PAD || ks < KS - 1 || 32 * ks + 8 * lg + 4 * hh < CT; };
 #pragma unroll
     for (int ks = 0; ks < KS; ++ks) {
-      const float4 p0 = real(ks, 0) ? *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg) : z4;
-      const float4 p1 = real(ks, 1) ? *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg + 4) : z4;
+      float4 p0, p1;
+      if (PROJ) {   // the attention half's output: accumulator rows = the channels this lane holds for k-step ks
+        const f32x4 q0 = acc[2 * ks][mt], q1 = acc[2 * ks + 1][mt];
+        p0 = make_float4(q0[0], q0[1], q0[2], q0[3]);
+        p1 = make_float4(q1[0], q1[1], q1[2], q1[3]);
+        // ... and they go on as residual + fc2 bias
+        const f32x4 c0 = real(ks, 0) ? *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        const f32x4 c1 = real(ks, 1) ? *reinterpret_cast<const f32x4*>(a.b2 + 32 * ks + 8 * lg + 4) : (f32x4){0.f, 0.f, 0.f, 0.f};
+        acc[2 * ks][mt] = q0 + c0;
+        acc[2 * ks + 1][mt] = q1 + c1;
+      } else {
+        p0 = real(ks, 0) ? *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg) : z4;
+        p1 = real(ks, 1) ? *reinterpret_cast<const float4*>(row + 32 * ks + 8 * lg + 4) : z4;
+      }
       v[ks][0] = p0.x; v[ks][1] = p0.y; v[ks][2] = p0.z; v[ks][3] = p0.w;
       v[ks][4] = p1.x; v[ks][5] = p1.y; v[ks][6] = p1.z; v[ks][7] = p1.w;
 #pragma unroll
@@ -118,11 +184,12 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
     }
   }
 
-  f32x4 acc[NT][2];
+  if (!PROJ) {
 #pragma unroll
-  for (int nt = 0; nt < NT; ++nt)
+    for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
-    for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+      for (int mt = 0; mt < 2; ++mt) acc[nt][mt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+  }
 
   // fragment byte offsets inside a chunk image (this lane)
   int w1_off[4];   // row nt*16+l15 of the W1 part, k-step 0; k-step s adds s*HC*64 bytes
@@ -213,6 +280,10 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
       const int ks = nt >> 1, hh = nt & 1;
       const int c = 32 * ks + 8 * lg + 4 * hh;
       if (PAD && ks == KS - 1 && c >= CT) continue;
+      if (PROJ) {   // residual and bias are in the accumulators already
+        *reinterpret_cast<f32x4*>(a.out + (size_t)tok * CT + c) = acc[nt][mt];
+        continue;
+      }
       const float4 bb = *reinterpret_cast<const float4*>(a.b2 + c);
       float4 r4;
       if (KEEPX) r4 = make_float4(xr[mt][ks][4 * hh], xr[mt][ks][4 * hh + 1], xr[mt][ks][4 * hh + 2], xr[mt][ks][4 * hh + 3]);
@@ -231,12 +302,34 @@ __global__ __launch_bounds__(256, 2) void k_mlp_fused(MlpArgs a) {
 
 // C = 96; C = 60 / 120 (head_dim-20 networks) on zero-padded 64 / 128-slot operands
 bool mlp_fused_supported(int C) { return C == 96 || C == 60 || C == 120; }
+// PROJ form: the head_dim-20 blocks whose attention core is k_wattn_ring<hd20>
+bool mlp_fused_proj_supported(int C) { return C == 60 || C == 120; }
+
+int launch_mlp_fused_proj(int C, int T, int L, const float* x_in, const bf16* o, int ldo, const float* cond, int cond_stride,
+                          int cond_off, const float* proj_b, float* out, const bf16* pimg, const bf16* img, const float* b1,
+                          const float* b2, const float* g, const float* b, hipStream_t s) {
+  if (!mlp_fused_proj_supported(C)) return SWG_E_UNSUPPORTED;
+  if (!x_in || !o || !cond || !proj_b || !out || !pimg || !img) return SWG_E_NULL;
+  if (L <= 0 || T % L || ldo < (C / 20) * 32 || ldo % 8) return SWG_E_SHAPE;
+  if (T <= 0) return 0;
+  MlpArgs a = {x_in, out, img, b1, b2, g, b, T, o, ldo, pimg, proj_b, cond, cond_stride, cond_off, L};
+  const int Cs = round_up(C, 32);
+  const size_t lds = (size_t)2 * (2 * HC * Cs) * 2 + (size_t)4 * Cs * sizeof(float);
+  SwgProfScope ps(KID_FUSED_MLP, 18.0 * T * (double)C * C, 10.0 * T * (double)C + 18.0 * C * C, s);
+  dim3 grid(cdiv(T, 128)), block(256);
+  static std::atomic<uint64_t> lds_ok{0};
+  if (int e = ensure_dyn_lds(lds_ok, (const void*)k_mlp_fused<128, false, 120, true>, (int)(2 * (2 * HC * 128) * 2 + 4 * 128 * 4))) return e;
+  if (C == 60) hipLaunchKernelGGL((k_mlp_fused<64, false, 60, true>), grid, block, lds, s, a);
+  else hipLaunchKernelGGL((k_mlp_fused<128, false, 120, true>), grid, block, lds, s, a);
+  SWG_LAUNCH_CHECK();
+  return 0;
+}
 
 int launch_mlp_fused(int C, int T, const float* x, float* out, const bf16* img, const float* b1, const float* b2,
                      const float* g, const float* b, hipStream_t s) {
   if (!mlp_fused_supported(C)) return SWG_E_UNSUPPORTED;
   if (T <= 0) return 0;
-  MlpArgs a = {x, out, img, b1, b2, g, b, T};
+  MlpArgs a = {x, out, img, b1, b2, g, b, T, nullptr, 0, nullptr, nullptr, nullptr, 0, 0, 1};
   const int Cs = round_up(C, 32);   // operand slots
   const size_t lds = (size_t)2 * (2 * HC * Cs) * 2 + (size_t)4 * Cs * sizeof(float);
   SwgProfScope ps(KID_FUSED_MLP, 16.0 * T * (double)C * C, 8.0 * T * (double)C + 16.0 * C * C, s);

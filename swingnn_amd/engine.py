@@ -272,6 +272,14 @@ def proj_frag_image(proj_w: torch.Tensor, heads: int, dtype=torch.bfloat16) -> t
     proj_w = proj_w.detach().float()
     Cdim = proj_w.shape[0]
     dev = proj_w.device
+    hd = Cdim // heads
+    if hd != 32:   # head_dim 20 (k_mlp_fused PROJ form): rows padded to 32 | Cs, every head's columns to a 32-slot group
+        cs = -(-Cdim // 32) * 32
+        pw = torch.zeros(cs, heads, 32, device=dev)
+        pw[:Cdim, :, :hd] = proj_w.reshape(Cdim, heads, hd)
+        wp = pw[..., _pi(dev)].reshape(cs, heads * 32)
+        w = wp[_rho(cs, dev)].reshape(cs // 16, 16, heads, 4, 8)                    # [nt, i, ks, lg, e]
+        return w.permute(2, 0, 3, 1, 4).reshape(-1).to(dtype).contiguous()
     wp = proj_w.reshape(Cdim, heads, 32)[..., _pi(dev)].reshape(Cdim, Cdim)        # columns in o's slot order
     w = wp[_rho(Cdim, dev)].reshape(Cdim // 16, 16, Cdim // 32, 4, 8)               # [nt, i, ks, lg, e]
     return w.permute(2, 0, 3, 1, 4).reshape(-1).to(dtype).contiguous()             # [ks, nt, lg, i, e]
@@ -283,6 +291,7 @@ RING192_FUSE_PROJ = os.environ.get("SWG_RING192_FUSE_PROJ", "0") == "1"
 # channel counts with the fused attention-tail + MLP kernel (csrc/mlp_stream.hip, PROJ form)
 PROJ_MLP_DIMS = (384,) if RING192_FUSE_PROJ else (384, 192)
 USE_FUSED_ATTN = True
+MLP_FUSED_PROJ = os.environ.get("SWG_MLP_FUSED_PROJ", "1") == "1"   # A/B knob: attention tail folded into k_mlp_fused (C = 60 / 120)
 RING_HD20 = os.environ.get("SWG_RING_HD20", "1") == "1"   # A/B knob: fused attention core for head_dim 20
 RING_SMALL_WINDOWS = os.environ.get("SWG_RING_SMALL_WINDOWS", "1") == "1"   # A/B knob: 4x4 / 2x2 windows at C = 192 / 384
 
@@ -361,6 +370,9 @@ def block_desc(keep: Keep, blk, cond_off: int) -> L.SwgBlock:
     pimg = None
     if USE_FUSED_MLP and blk.dim in FUSED_MLP_DIMS:
         img = _ptr(keep.image(mlp_image, (blk.mlp.fc1.weight, blk.mlp.fc2.weight)))
+        if aimg is not None and blk.dim in (60, 120) and MLP_FUSED_PROJ:
+            # head_dim-20 blocks: the projection as fragments for the PROJ form of k_mlp_fused (swg_block_fwd)
+            pimg = _ptr(keep.image(proj_frag_image, (blk.attn.proj.weight,), blk.num_heads))
     elif (USE_FUSED_MLP and blk.dim in PROJ_MLP_DIMS and aimg is not None and not RING_ATTN_FUSED_PROJ[blk.dim]
           and blk.dim in STREAM_MLP_HC):
         # projection fragments + MLP stream in one allocation: the fused kernel streams across the seam, the plain
