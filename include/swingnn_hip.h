@@ -60,10 +60,11 @@ typedef struct swg_block {
    * 32-slot group, channels to a multiple of 32) -- the slot-permuted Wproj [C, heads * 32] behind the stream for the
    * projection GEMM / the fused tail.  NULL -> the 4-kernel path (qkv GEMM, k_wattn_core, projection GEMM) is used. */
   const void* attn_img;
-  /* optional derived cache for the fused attention-tail + MLP kernel (C = 384): the projection weight as MFMA
-   * fragments (k-step major, rho-ordered out tiles, input columns in the slot order of the attention output)
-   * immediately followed by the mlp_stream image (swingnn_amd/engine.py proj_mlp_image).  NULL -> projection GEMM +
-   * MLP kernel. */
+  /* optional derived cache for the fused attention-tail + MLP kernel: the projection weight as MFMA fragments (k-step
+   * major, rho-ordered out tiles, input columns in the slot order of the attention output; swingnn_amd/engine.py
+   * proj_frag_image).  C = 192 / 384: immediately followed by the mlp_stream image (one allocation, mlp_img points at
+   * its second half).  C = 60 / 120 (head_dim 20): the fragments alone, rows padded to 64 / 128, one 32-slot column
+   * group per head (mlp_img is the k_mlp_fused image).  NULL -> projection GEMM + MLP kernel. */
   const void* proj_mlp_img;
   /* optional derived cache for k_wattn_ring at 6x6 windows: the relative-position bias (:121-124) of every head in
    * ACCUMULATOR layout, [heads][3 key tiles][3 query tiles][64 lanes] x 4 fp32, scaled by log2(e), -3e38 on padded
@@ -190,7 +191,7 @@ int swg_patch_embed_fwd(const swg_net* net, int32_t B, const float* x, const flo
 int swg_wattn_fwd(const swg_block* blk, int32_t B, const float* x_in, const float* cond, int32_t cond_stride,
                   float* x_out, void* ws, size_t ws_bytes, void* stream);
 /* One SwinTransformerBlock.forward (model/swin_gnn/swin_gnn.py:232-277) = swg_wattn_fwd then swg_ln_mlp_fwd; where
- * the block carries proj_mlp_img (C = 384) the projection, the shortcut and the MLP half run as one kernel behind the
+ * the block carries proj_mlp_img (C = 192 / 384; 60 / 120 at head_dim 20) the projection, the shortcut and the MLP half run as one kernel behind the
  * attention core.  x_in == x_out allowed.  This is what the network pass (swg_precond_forward) runs per block. */
 int swg_block_fwd(const swg_block* blk, int32_t B, const float* x_in, const float* cond, int32_t cond_stride,
                   float* x_out, void* ws, size_t ws_bytes, void* stream);
